@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- rendered 256x256 patches/s (fwd+bwd rendering loss) on N MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input:
+``loss = RenderingLoss(LocalRenderer())(input, target); loss.backward()`` -- scene
+sampling on the host (reference RNG order), one H2D copy of the [B,S,9] scene table, the
+fused K3 kernel (both renderings, log/L1, analytic backward) and the loss finalise.
+Inputs are resident in HBM before the timed region starts.
+
+Workload = BASELINE.json configs[1]: synthetic 256x256 SVBRDF maps, 9 light/view samples
+(3 random + 6 specular), per-GPU batch 8, fp32.  N > 1: one process per GPU (torchrun),
+batch sharded by rank, NO data-path collective (the path is embarrassingly parallel);
+the only collectives are the barrier and the MAX over ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
+(HBM-bound accounting of the dominant kernel k_rendering_loss: algorithmic bytes
+144*H*W per patch / measured launch duration) and `cpu_baseline` (the eager-PyTorch
+restatement of the reference's algorithm, oracle/eager_torch.py, timed on this box's
+host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_VALU_PEAK_TFLOPS = 157.3   # ditto, packed-FMA vector peak
+FLOP_PER_PIXEL_SCENE = 573.0    # SURVEY.md 8d (div/sqrt/log/pow counted as 1)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (config 2: 8)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--random-scenes", type=int, default=3)
+    ap.add_argument("--specular-scenes", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
+    return ap.parse_args()
+
+
+def synthetic_maps(gen, B, H):
+    """normals = normalize(0.3N, 0.3N, 1+|0.3N|); diffuse, specular ~ U(0,1);
+    roughness ~ U(0,1) one channel tiled x3."""
+    n = torch.randn(B, 3, H, H, generator=gen) * 0.3
+    n[:, 2] = 1.0 + n[:, 2].abs()
+    n = n / n.norm(dim=1, keepdim=True)
+    d = torch.rand(B, 3, H, H, generator=gen)
+    r = torch.rand(B, 1, H, H, generator=gen).expand(B, 3, H, H)
+    s = torch.rand(B, 3, H, H, generator=gen)
+    return torch.cat((n, d, r, s), dim=1).contiguous()
+
+
+def cpu_baseline(args, inp, tgt, table):
+    """Eager-PyTorch port of the reference's algorithm on the host cores (bounded sample)."""
+    from oracle import eager_torch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    nb = min(2, inp.shape[0])
+    xi = inp[:nb].clone().requires_grad_(True)
+    eager_torch.rendering_loss(xi, tgt[:nb], table[:nb]).backward()      # warm-up
+    done, t0 = 0, time.perf_counter()
+    while True:
+        xi = inp[:nb].clone().requires_grad_(True)
+        eager_torch.rendering_loss(xi, tgt[:nb], table[:nb]).backward()
+        done += nb
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or done >= 64:
+            break
+    res = {"value": done / el, "unit": "patches/s", "cores": cores, "kind": "port",
+           "sample": "%d patches of %dx%d, S=%d, fwd+bwd, eager PyTorch (oracle/eager_torch.py), %.1f s"
+                     % (done, args.size, args.size, table.shape[1], el)}
+    try:   # the plain-C oracle on all cores, for orientation
+        from oracle import c_oracle
+        c_oracle.set_threads(cores)
+        a, b, c = inp[:nb].numpy(), tgt[:nb].numpy(), table[:nb].numpy()
+        c_oracle.rendering_loss(a, b, c)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 3.0:
+            c_oracle.rendering_loss(a, b, c)
+            reps += 1
+        res["c_oracle_patches_per_s"] = reps * nb / (time.perf_counter() - t0)
+        res["c_oracle_threads"] = c_oracle.max_threads()
+    except Exception as e:  # pragma: no cover
+        res["c_oracle_error"] = repr(e)
+    return res
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm
+
+    from svbrdf_estimation_amd import _native, distributed, losses, renderers
+
+    B, H, S = args.batch, args.size, args.random_scenes + args.specular_scenes
+    gen = torch.Generator().manual_seed(distributed.rank_seed(1234, rank))
+    inp_h, tgt_h = synthetic_maps(gen, B, H), synthetic_maps(gen, B, H)
+    inp = inp_h.to(dev).requires_grad_(True)
+    tgt = tgt_h.to(dev)
+    loss_fn = losses.RenderingLoss(renderers.LocalRenderer())
+    loss_fn.random_configuration_count = args.random_scenes
+    loss_fn.specular_configuration_count = args.specular_scenes
+    torch.manual_seed(distributed.rank_seed(313, rank))    # per-rank scene RNG
+
+    # HIP events around the kernel launches of every timed step, on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    state = {"i": -1}
+
+    def hook(phase):
+        i = state["i"]
+        if 0 <= i < len(ev):
+            ev[i][0 if phase == "begin" else 1].record(torch.cuda.current_stream(dev))
+    _native.set_launch_hook(hook)
+
+    def step():
+        inp.grad = None
+        loss = loss_fn(inp, tgt)
+        loss.backward()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        state["i"] = i
+        last = step()
+    state["i"] = -1
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    _native.set_launch_hook(None)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        mean_loss = distributed.global_mean(last.detach()).item()
+    else:
+        mean_loss = last.item()
+
+    kernel_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+
+    if rank == 0:
+        patches = world * B * args.steps
+        alg_bytes = 144.0 * H * H * B                 # per launch: 36 planes x 4 B per patch
+        achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "k3_hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("B") == B and tj.get("H") == H and tj.get("S") == S:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)",
+            "value": patches / elapsed, "unit": "patches/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic %dx%d 12-channel SVBRDF maps, %d light/view "
+                                   "samples (%d random + %d specular), per-GPU batch %d, RenderingLoss fwd+bwd"
+                                   % (H, H, S, args.random_scenes, args.specular_scenes, B),
+                       "global_batch": world * B, "H": H, "W": H, "scenes": S,
+                       "parallelism": "batch-sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "k_rendering_loss<VEC,true> (+ k_loss_finalize, same event pair)",
+                         "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "valu_frac_of_fp32_peak": (FLOP_PER_PIXEL_SCENE * H * H * S * B / (kernel_ms_avg * 1e-3))
+                                                   / (FP32_VALU_PEAK_TFLOPS * 1e12)},
+            "loss": mean_loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            table = loss_fn.sample_scene_table(B)
+            out["cpu_baseline"] = cpu_baseline(args, inp_h, tgt_h, table)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+/*
+ * svbrdf_hip.h -- C ABI of libsvbrdf_hip.so, the MI355X (gfx950) rendering-loss engine.
+ *
+ * Drop-in boundary for ONE hot path of mworchel/svbrdf-estimation:
+ *     LocalRenderer.render            development/multiImage_pytorch/renderers.py:67-104
+ *     RenderingLoss.forward (+autograd backward)
+ *                                     development/multiImage_pytorch/losses.py:29-52
+ * The reference has no FFI (it is pure PyTorch); the "binding" a maintainer adds is
+ * the ctypes stub shown in INTEGRATION.md, which replaces the bodies of those two
+ * methods.  Signatures use plain pointers and sizes only -- no torch types.
+ *
+ * Conventions
+ *   - every pointer except `workspace`/`xrow_host` is DEVICE memory owned by the
+ *     caller, C-contiguous fp32, 4-byte aligned (16-byte alignment enables the
+ *     vectorised path; anything else takes the scalar path -- same results).
+ *   - layouts:  maps/input/target/grad  [B,12,H,W]  channel order
+ *               normals(0:3) diffuse(3:6) roughness(6:9) specular(9:12)
+ *               (utils.py:36-58 pack_svbrdf/unpack_svbrdf)
+ *               scenes  [B,S,9] = camera xyz | light xyz | light rgb   per render
+ *               (environment.py:4-16 Camera/Light/Scene)
+ *               xrow    [W]     = torch.linspace(-1, 1, W)  (renderers.py:73); pixel
+ *               (i,j) sits at (xrow[j], -xrow[i], 0) (renderers.py:74-76), so H == W.
+ *               renderings / grad_out [B,S,3,H,W]
+ *   - the library never allocates, frees or retains device memory and never
+ *     synchronises; kernels are enqueued on `stream` (a hipStream_t; NULL = the
+ *     default stream) and the call returns immediately.
+ *   - return value: 0 success; <0 argument error (-1 null pointer, -2 bad dims or
+ *     H != W, -3 misaligned pointer, -4 workspace too small); >0 hipError_t of the
+ *     launch.  svbrdf_last_error() gives a thread-local message.
+ *   - stateless and re-entrant; results are bitwise run-to-run reproducible (fixed
+ *     shape two-stage loss reduction, no float atomics).
+ */
+#ifndef SVBRDF_HIP_H
+#define SVBRDF_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVBRDF_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define SVBRDF_API __attribute__((visibility("default")))
+#else
+#define SVBRDF_API
+#endif
+
+#define SVBRDF_OK 0
+#define SVBRDF_ERR_NULL (-1)
+#define SVBRDF_ERR_DIMS (-2)
+#define SVBRDF_ERR_ALIGN (-3)
+#define SVBRDF_ERR_WORKSPACE (-4)
+
+SVBRDF_API int svbrdf_abi_version(void);
+
+/* thread-local, static storage; valid until the next failing call on this thread */
+SVBRDF_API const char *svbrdf_last_error(void);
+
+/* Host helper: fills xrow_host[W] (HOST memory) with the bit pattern of
+ * torch.linspace(-1, 1, W) as the reference's CPU path produces it
+ * (renderers.py:73).  Upload it once per W. */
+SVBRDF_API int svbrdf_make_xrow(float *xrow_host, int W);
+
+/* K1 -- replaces LocalRenderer.render (renderers.py:67-104), S scenes per map in
+ * one launch: out[b,s] = render(scene[b,s], maps[b]). */
+SVBRDF_API int svbrdf_render_fwd(const float *maps, const float *scenes, const float *xrow,
+                      float *out, int B, int S, int H, int W, void *stream);
+
+/* K2 -- replaces the autograd graph of render(): grad_maps[b] = sum_s J(b,s)^T
+ * grad_out[b,s]; grad_maps is overwritten. */
+SVBRDF_API int svbrdf_render_bwd(const float *maps, const float *scenes, const float *xrow,
+                      const float *grad_out, float *grad_maps,
+                      int B, int S, int H, int W, void *stream);
+
+/* bytes of device scratch svbrdf_rendering_loss_fwd_bwd needs for these dims */
+SVBRDF_API size_t svbrdf_rendering_loss_workspace_bytes(int B, int S, int H, int W);
+
+/* K3 -- replaces RenderingLoss.forward AND its backward (losses.py:29-52):
+ *   loss_out[0] = mean_{b,s,c,i,j} | log(render(input)+eps) - log(render(target)+eps) |
+ *   grad_input  = d loss / d input  (for upstream gradient 1.0), or NULL for
+ *                 forward-only.
+ * `scenes` are the light/view samples the caller drew (losses.py:35). */
+SVBRDF_API int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *target,
+                                  const float *scenes, const float *xrow, float eps,
+                                  float *loss_out, float *grad_input,
+                                  void *workspace, size_t workspace_bytes,
+                                  int B, int S, int H, int W, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVBRDF_HIP_H */

@@ -1,0 +1,195 @@
+"""ctypes binding of libsvbrdf_hip.so (C ABI: include/svbrdf_hip.h).
+
+PyTorch is used here only for device memory, the current HIP stream and (elsewhere)
+autograd glue.  No arithmetic of the hot path happens in Python.  If the shared
+library is missing or fails to load, every entry point raises NativeLibraryError --
+there is deliberately no fallback.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "lib", "libsvbrdf_hip.so")
+ABI_VERSION = 1
+
+_lock = threading.Lock()
+_lib = None
+_xrow_cache = {}
+_workspace_cache = {}
+_launch_hook = None
+
+
+def set_launch_hook(fn):
+    """Measurement aid: ``fn("begin")`` / ``fn("end")`` is called immediately before / after the
+    kernel launches of the fused loss are enqueued (bench.py records HIP events there).
+    None disables it.  No effect on results."""
+    global _launch_hook
+    _launch_hook = fn
+
+
+class NativeLibraryError(RuntimeError):
+    """libsvbrdf_hip.so is missing, stale or reported an error."""
+
+
+def library_path():
+    return _SO
+
+
+_fp = ctypes.c_void_p
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_SO):
+            raise NativeLibraryError(
+                "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C svbrdf_estimation_amd/csrc`. There is no CPU fallback." % _SO)
+        try:
+            # torch is imported first on purpose: its bundled libamdhip64.so.7 is then the
+            # one HIP runtime of the process and our NEEDED entry resolves to it by SONAME,
+            # so the stream handles torch hands us belong to the runtime that launches.
+            lib = ctypes.CDLL(_SO)
+        except OSError as e:  # pragma: no cover
+            raise NativeLibraryError("cannot load %s: %s" % (_SO, e))
+        lib.svbrdf_abi_version.restype = ctypes.c_int
+        lib.svbrdf_last_error.restype = ctypes.c_char_p
+        lib.svbrdf_make_xrow.argtypes = [_fp, ctypes.c_int]
+        lib.svbrdf_render_fwd.argtypes = [_fp, _fp, _fp, _fp] + [ctypes.c_int] * 4 + [_fp]
+        lib.svbrdf_render_bwd.argtypes = [_fp, _fp, _fp, _fp, _fp] + [ctypes.c_int] * 4 + [_fp]
+        lib.svbrdf_rendering_loss_workspace_bytes.argtypes = [ctypes.c_int] * 4
+        lib.svbrdf_rendering_loss_workspace_bytes.restype = ctypes.c_size_t
+        lib.svbrdf_rendering_loss_fwd_bwd.argtypes = (
+            [_fp, _fp, _fp, _fp, ctypes.c_float, _fp, _fp, _fp, ctypes.c_size_t] + [ctypes.c_int] * 4 + [_fp])
+        for name in ("svbrdf_make_xrow", "svbrdf_render_fwd", "svbrdf_render_bwd", "svbrdf_rendering_loss_fwd_bwd"):
+            getattr(lib, name).restype = ctypes.c_int
+        v = lib.svbrdf_abi_version()
+        if v != ABI_VERSION:
+            raise NativeLibraryError("ABI mismatch: library %d, binding %d -- rebuild" % (v, ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = _load().svbrdf_last_error()
+        raise NativeLibraryError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def make_xrow_host(W):
+    """torch.linspace(-1, 1, W) bit pattern of the reference's CPU path (renderers.py:73)."""
+    buf = (ctypes.c_float * W)()
+    _check(_load().svbrdf_make_xrow(ctypes.cast(buf, _fp), W), "svbrdf_make_xrow")
+    return torch.tensor(list(buf), dtype=torch.float32)
+
+
+def _require_device_f32(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise NativeLibraryError(
+            "%s is on %s: the MI355X engine only computes on a ROCm device (no CPU fallback)" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
+
+
+def xrow(device, W):
+    key = (device.index, W)
+    t = _xrow_cache.get(key)
+    if t is None:
+        t = make_xrow_host(W).to(device)
+        _xrow_cache[key] = t
+    return t
+
+
+def _workspace(device, nbytes):
+    # one scratch buffer per (device, stream): calls on different streams never share it
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _workspace_cache.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        t = torch.empty((max(nbytes, 4096) + 3) // 4, dtype=torch.float32, device=device)
+        _workspace_cache[key] = t
+    return t
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _dims(maps, scenes):
+    if maps.dim() != 4 or maps.shape[1] != 12:
+        raise ValueError("maps must be [B,12,H,W], got %s" % (tuple(maps.shape),))
+    B, _, H, W = maps.shape
+    if H != W:
+        raise ValueError("H must equal W (got %dx%d): the reference transposes the x grid, renderers.py:75" % (H, W))
+    if scenes.dim() != 3 or scenes.shape[0] != B or scenes.shape[2] != 9:
+        raise ValueError("scenes must be [B,S,9], got %s for B=%d" % (tuple(scenes.shape), B))
+    return B, scenes.shape[1], H, W
+
+
+def render_fwd(maps, scenes):
+    """K1: maps [B,12,H,W], scenes [B,S,9] (device) -> renderings [B,S,3,H,W]."""
+    _require_device_f32(maps, "maps")
+    _require_device_f32(scenes, "scenes")
+    maps, scenes = maps.contiguous(), scenes.contiguous()
+    B, S, H, W = _dims(maps, scenes)
+    out = torch.empty((B, S, 3, H, W), dtype=torch.float32, device=maps.device)
+    with torch.cuda.device(maps.device):
+        _check(_load().svbrdf_render_fwd(maps.data_ptr(), scenes.data_ptr(), xrow(maps.device, W).data_ptr(),
+                                         out.data_ptr(), B, S, H, W, _stream(maps.device)), "svbrdf_render_fwd")
+    return out
+
+
+def render_bwd(maps, scenes, grad_out):
+    """K2: adjoint of render_fwd -> grad_maps [B,12,H,W]."""
+    _require_device_f32(maps, "maps")
+    _require_device_f32(scenes, "scenes")
+    _require_device_f32(grad_out, "grad_out")
+    maps, scenes, grad_out = maps.contiguous(), scenes.contiguous(), grad_out.contiguous()
+    B, S, H, W = _dims(maps, scenes)
+    if tuple(grad_out.shape) != (B, S, 3, H, W):
+        raise ValueError("grad_out must be [B,S,3,H,W]")
+    grad = torch.empty_like(maps)
+    with torch.cuda.device(maps.device):
+        _check(_load().svbrdf_render_bwd(maps.data_ptr(), scenes.data_ptr(), xrow(maps.device, W).data_ptr(),
+                                         grad_out.data_ptr(), grad.data_ptr(), B, S, H, W, _stream(maps.device)),
+               "svbrdf_render_bwd")
+    return grad
+
+
+def rendering_loss(input, target, scenes, eps=0.1, want_grad=True):
+    """K3: fused loss (+ d loss/d input).  Returns (loss [1] device tensor, grad or None)."""
+    _require_device_f32(input, "input")
+    _require_device_f32(target, "target")
+    _require_device_f32(scenes, "scenes")
+    if input.shape != target.shape:
+        raise ValueError("input and target shapes differ: %s vs %s" % (tuple(input.shape), tuple(target.shape)))
+    if target.device != input.device or scenes.device != input.device:
+        raise ValueError("input, target and scenes must be on the same device")
+    input, target, scenes = input.contiguous(), target.contiguous(), scenes.contiguous()
+    B, S, H, W = _dims(input, scenes)
+    lib = _load()
+    nbytes = lib.svbrdf_rendering_loss_workspace_bytes(B, S, H, W)
+    ws = _workspace(input.device, nbytes)
+    loss = torch.empty(1, dtype=torch.float32, device=input.device)
+    grad = torch.empty_like(input) if want_grad else None
+    xr = xrow(input.device, W)
+    hook = _launch_hook
+    with torch.cuda.device(input.device):
+        if hook is not None:
+            hook("begin")
+        rc = lib.svbrdf_rendering_loss_fwd_bwd(
+            input.data_ptr(), target.data_ptr(), scenes.data_ptr(), xr.data_ptr(),
+            ctypes.c_float(eps), loss.data_ptr(), grad.data_ptr() if want_grad else None,
+            ws.data_ptr(), ws.numel() * 4, B, S, H, W, _stream(input.device))
+        if hook is not None:
+            hook("end")
+    _check(rc, "svbrdf_rendering_loss_fwd_bwd")
+    return loss, grad

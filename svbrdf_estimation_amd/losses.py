@@ -1,0 +1,107 @@
+"""Losses with the reference's names and semantics (development/multiImage_pytorch/losses.py).
+
+``RenderingLoss(renderer).forward(input, target)`` (losses.py:21-52): per batch item draw
+``random_configuration_count`` + ``specular_configuration_count`` scenes from torch's global
+CPU generator, render input and target under each, ``log(x + 0.1)``, L1 mean.  When the
+injected renderer is this package's ``LocalRenderer`` the whole thing -- both renderings,
+the log/L1 and the analytic backward w.r.t. ``input`` -- is ONE fused HIP kernel (K3) that
+reads the 24 map planes once and writes the 12 gradient planes once.  Any other object
+with a ``.render(scene, svbrdf)`` method (the reference's plugin protocol, e.g. a path
+tracer) goes through the generic per-scene loop built from that renderer's own outputs.
+"""
+import torch
+import torch.nn as nn
+
+from . import _native, environment, renderers, utils
+
+
+class SVBRDFL1Loss(nn.Module):
+    """losses.py:7-19: L1 on normals and roughness, L1 on log(x+0.01) for diffuse/specular."""
+
+    epsilon_l1 = 0.01
+
+    def forward(self, input, target):
+        i_n, i_d, i_r, i_s = torch.split(input, (3, 3, 3, 3), dim=-3)
+        t_n, t_d, t_r, t_s = torch.split(target, (3, 3, 3, 3), dim=-3)
+        l1 = nn.functional.l1_loss
+        e = self.epsilon_l1
+        return (l1(i_n, t_n) + l1(torch.log(i_d + e), torch.log(t_d + e)) + l1(i_r, t_r)
+                + l1(torch.log(i_s + e), torch.log(t_s + e)))
+
+
+class _FusedRenderingLoss(torch.autograd.Function):
+    """K3 behind autograd: the kernel already produces d loss/d input for upstream grad 1."""
+
+    @staticmethod
+    def forward(ctx, input, target, scenes, eps):
+        need_in = ctx.needs_input_grad[0]
+        need_tg = ctx.needs_input_grad[1]
+        loss, grad_in = _native.rendering_loss(input, target, scenes, eps, want_grad=need_in)
+        grad_tg = None
+        if need_tg:
+            # |log a - log b| is symmetric: the target's gradient is the same kernel with roles swapped
+            _, grad_tg = _native.rendering_loss(target, input, scenes, eps, want_grad=True)
+        ctx.grads = (grad_in, grad_tg)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        grad_in, grad_tg = ctx.grads
+        ctx.grads = None
+        gi = grad_in * grad_loss if grad_in is not None else None
+        gt = grad_tg * grad_loss if grad_tg is not None else None
+        return gi, gt, None, None
+
+
+class RenderingLoss(nn.Module):
+    epsilon_render = 0.1   # losses.py:45
+
+    def __init__(self, renderer):
+        super().__init__()
+        self.renderer = renderer
+        self.random_configuration_count = 3     # losses.py:26
+        self.specular_configuration_count = 6   # losses.py:27
+
+    def sample_scene_table(self, batch_size):
+        """[B,S,9] on the host, reference RNG draw order (one item after the other)."""
+        return torch.stack([environment.scene_table(self.random_configuration_count,
+                                                    self.specular_configuration_count)
+                            for _ in range(batch_size)], dim=0)
+
+    def forward(self, input, target):
+        if input.dim() != 4 or input.shape != target.shape:
+            raise ValueError("input and target must both be [B,12,H,W]")
+        if isinstance(self.renderer, renderers.LocalRenderer):
+            table = self.sample_scene_table(input.shape[0])
+            if not input.is_cuda:
+                raise _native.NativeLibraryError(
+                    "RenderingLoss with the MI355X LocalRenderer needs tensors on a ROCm device "
+                    "(got %s); there is no CPU fallback" % input.device)
+            return _FusedRenderingLoss.apply(input, target, table.to(input.device, non_blocking=True),
+                                             self.epsilon_render)
+        return self._forward_plugin(input, target)
+
+    def _forward_plugin(self, input, target):
+        """Generic plugin path for a foreign renderer object (losses.py:29-52 semantics)."""
+        rendered_in, rendered_tg = [], []
+        for b in range(input.shape[0]):
+            scenes = (environment.generate_random_scenes(self.random_configuration_count)
+                      + environment.generate_specular_scenes(self.specular_configuration_count))
+            rendered_in.append(torch.cat([self.renderer.render(sc, input[b]) for sc in scenes], dim=0))
+            rendered_tg.append(torch.cat([self.renderer.render(sc, target[b]) for sc in scenes], dim=0))
+        a = torch.log(torch.stack(rendered_in, dim=0) + self.epsilon_render)
+        t = torch.log(torch.stack(rendered_tg, dim=0) + self.epsilon_render)
+        return nn.functional.l1_loss(a, t)
+
+
+class MixedLoss(nn.Module):
+    """losses.py:54-63: l1_weight * SVBRDFL1Loss + RenderingLoss."""
+
+    def __init__(self, renderer, l1_weight=0.1):
+        super().__init__()
+        self.l1_weight = l1_weight
+        self.l1_loss = SVBRDFL1Loss()
+        self.rendering_loss = RenderingLoss(renderer)
+
+    def forward(self, input, target):
+        return self.l1_weight * self.l1_loss(input, target) + self.rendering_loss(input, target)

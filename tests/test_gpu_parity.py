@@ -1,0 +1,321 @@
+"""GPU parity tests proper: the HIP kernels, called through the C ABI (ctypes) and through
+the reference-shaped Python interface, against the C oracle and the golden fixtures."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from tolerances import (assert_grad_close, assert_loss_close, assert_render_strict,
+                        assert_render_vs_reference)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X (select CPU tests with -m 'not gpu')"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def native():
+    from svbrdf_estimation_amd import _native
+    _native._load()
+    return _native
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ---------------------------------------------------------------- raw C ABI
+
+def test_abi_render_fwd_bwd_raw_ctypes(dev, native, oracle):
+    """calls the exported symbols directly with device pointers, as a C host would"""
+    lib = native._load()
+    B, S, H = 2, 3, 32
+    maps = synth.make_maps(5, B, H, tiled_roughness=False)
+    torch.manual_seed(1)
+    from svbrdf_estimation_amd import environment
+    table = torch.stack([environment.scene_table(1, 2) for _ in range(B)]).numpy()
+    xrow = np.empty(H, np.float32)
+    assert lib.svbrdf_make_xrow(xrow.ctypes.data_as(ctypes.c_void_p), H) == 0
+    assert np.array_equal(xrow, oracle.make_xrow(H))
+    d_maps, d_sc, d_x = _t(maps, dev), _t(table, dev), _t(xrow, dev)
+    d_out = torch.empty(B, S, 3, H, H, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.svbrdf_render_fwd(d_maps.data_ptr(), d_sc.data_ptr(), d_x.data_ptr(), d_out.data_ptr(), B, S, H, H, st)
+    assert rc == 0, lib.svbrdf_last_error()
+    torch.cuda.synchronize()
+    assert_render_strict(_np(d_out), oracle.render_fwd(maps, table), "raw render_fwd")
+    cot = synth.uniform01(6, (B, S, 3, H, H)) - np.float32(0.5)
+    d_cot, d_g = _t(cot, dev), torch.empty(B, 12, H, H, device=dev)
+    rc = lib.svbrdf_render_bwd(d_maps.data_ptr(), d_sc.data_ptr(), d_x.data_ptr(), d_cot.data_ptr(), d_g.data_ptr(),
+                               B, S, H, H, st)
+    assert rc == 0, lib.svbrdf_last_error()
+    torch.cuda.synchronize()
+    assert_grad_close(_np(d_g), oracle.render_bwd(maps, table, cot), "raw render_bwd")
+
+
+def test_abi_error_codes(dev, native):
+    lib = native._load()
+    t = torch.zeros(12 * 16, device=dev)
+    p = t.data_ptr()
+    assert lib.svbrdf_render_fwd(None, p, p, p, 1, 1, 4, 4, None) == -1
+    assert lib.svbrdf_render_fwd(p, p, p, p, 1, 1, 4, 8, None) == -2
+    assert lib.svbrdf_render_fwd(p, p, p, p, 0, 1, 4, 4, None) == -2
+    assert lib.svbrdf_render_fwd(p + 2, p, p, p, 1, 1, 4, 4, None) == -3
+    need = lib.svbrdf_rendering_loss_workspace_bytes(1, 1, 4, 4)
+    assert need >= 4
+    assert lib.svbrdf_rendering_loss_fwd_bwd(p, p, p, p, ctypes.c_float(0.1), p, p, p, need - 1, 1, 1, 4, 4, None) == -4
+    assert b"workspace" in lib.svbrdf_last_error()
+
+
+# ---------------------------------------------------------------- K1 / K2 vs oracle and goldens
+
+@pytest.mark.parametrize("name", ["g1_render_64.npz", "g1_render_32_tiled.npz"])
+def test_render_forward_golden(dev, native, oracle, golden, name):
+    g = golden(name)
+    maps, sc = g["maps"][None], g["scenes"][None]
+    out = _np(native.render_fwd(_t(maps, dev), _t(sc, dev)))[0]
+    assert_render_strict(out, oracle.render_fwd(maps, sc)[0], name + " vs oracle")
+    assert_render_vs_reference(out, g["out"], oracle.render_fwd(maps, sc, f64=True)[0], name + " vs reference")
+
+
+@pytest.mark.parametrize("H", [256, 512])
+def test_render_forward_full_size(dev, native, oracle, golden, H):
+    g = golden("g2_render_lattice_%d.npz" % H)
+    maps = synth.make_maps(int(g["synth_seed"]), 1, H)
+    assert synth.checksum(maps[0]) == str(g["maps_sha256"])
+    sc, st = g["scenes"][None], int(g["stride"])
+    out = _np(native.render_fwd(_t(maps, dev), _t(sc, dev)))[0]
+    ref32, ref64 = oracle.render_fwd(maps, sc)[0], oracle.render_fwd(maps, sc, f64=True)[0]
+    assert_render_strict(out, ref32, "full %d vs oracle" % H)
+    assert_render_vs_reference(out[:, :, ::st, ::st], g["out_lattice"], ref64[:, :, ::st, ::st],
+                               "lattice %d vs reference" % H, scale=float(g["out_max"]))
+    np.testing.assert_allclose(out.astype(np.float64).sum(axis=(2, 3)), g["plane_sums"], rtol=2e-6)
+
+
+def test_kat(dev, native, golden):
+    g = golden("g9_kat.npz")
+    for k in ("kat1", "kat2"):
+        m, sc = g[k + "_maps"][None], g[k + "_scene"][None, None]
+        out = _np(native.render_fwd(_t(m, dev), _t(sc, dev)))[0]
+        np.testing.assert_allclose(out, g[k + "_out"], rtol=1e-6, atol=0)
+        grad = _np(native.render_bwd(_t(m, dev), _t(sc, dev), torch.ones(1, 1, 3, 2, 2, device=dev)))[0]
+        assert_grad_close(grad, g[k + "_grad_of_sum"], k + " grad", rtol=1e-5, afrac=1e-6)
+
+
+def test_edge_cases(dev, native, oracle, golden):
+    g = golden("g4_edge_cases.npz")
+    for name in g["names"]:
+        m, sc = g[name + "__maps"][None], g[name + "__scene"][None, None]
+        out = _np(native.render_fwd(_t(m, dev), _t(sc, dev)))[0]
+        ref = g[name + "__out"]
+        if np.abs(ref).max() == 0:
+            assert not out.any(), name
+        else:
+            assert_render_strict(out, oracle.render_fwd(m, sc)[0], name + " vs oracle")
+            assert_render_vs_reference(out, ref, oracle.render_fwd(m, sc, f64=True)[0], name)
+        grad = _np(native.render_bwd(_t(m, dev), _t(sc, dev), _t(g[name + "__cot"][None], dev)))[0]
+        if np.abs(g[name + "__grad"]).max() == 0:
+            assert not grad.any(), name
+        else:
+            assert_grad_close(grad, g[name + "__grad"], name + " grad vs reference")
+            assert_grad_close(grad, oracle.render_bwd(m, sc, g[name + "__cot"][None])[0], name + " grad vs oracle")
+    m, sc = g["r_below_clamp__maps"][None], g["r_below_clamp__scene"][None, None]
+    grad = _np(native.render_bwd(_t(m, dev), _t(sc, dev), _t(g["r_below_clamp__cot"][None], dev)))[0]
+    H = m.shape[-1]
+    assert not grad[7:9, :, : H // 2].any() and not grad[6, 1:, : H // 2].any()
+    assert grad[6, 0, 0] != 0
+
+
+@pytest.mark.parametrize("H", [7, 17, 30, 100])
+def test_ragged_sizes_all_vector_widths(dev, native, oracle, H, monkeypatch):
+    """odd / non-multiple-of-4 widths force the scalar path; even ones the vector paths"""
+    B, S = 2, 4
+    maps = synth.make_maps(40 + H, B, H, tiled_roughness=False)
+    torch.manual_seed(H)
+    from svbrdf_estimation_amd import environment
+    table = torch.stack([environment.scene_table(2, 2) for _ in range(B)]).numpy()
+    cot = synth.uniform01(H, (B, S, 3, H, H)) - np.float32(0.5)
+    ref_out = oracle.render_fwd(maps, table)
+    ref_g = oracle.render_bwd(maps, table, cot)
+    tgt = synth.make_maps(41 + H, B, H)
+    ref_l, ref_lg = oracle.rendering_loss(maps, tgt, table)
+    for vec in ("1", "2", "4"):
+        for k in ("SVBRDF_K1_VEC", "SVBRDF_K2_VEC", "SVBRDF_K3_VEC"):
+            monkeypatch.setenv(k, vec)
+        assert_render_strict(_np(native.render_fwd(_t(maps, dev), _t(table, dev))), ref_out, "fwd H=%d vec=%s" % (H, vec))
+        assert_grad_close(_np(native.render_bwd(_t(maps, dev), _t(table, dev), _t(cot, dev))), ref_g,
+                          "bwd H=%d vec=%s" % (H, vec))
+        l, lg = native.rendering_loss(_t(maps, dev), _t(tgt, dev), _t(table, dev))
+        assert_loss_close(l.item(), ref_l, "loss H=%d vec=%s" % (H, vec))
+        assert_grad_close(_np(lg), ref_lg, "loss grad H=%d vec=%s" % (H, vec))
+
+
+# ---------------------------------------------------------------- K3 fused loss
+
+@pytest.mark.parametrize("name", ["g3_loss_48.npz", "g3_loss_7_s5.npz"])
+def test_rendering_loss_golden(dev, native, oracle, golden, name):
+    g = golden(name)
+    loss, grad = native.rendering_loss(_t(g["input"], dev), _t(g["target"], dev), _t(g["scenes"], dev))
+    ref_l, ref_g = oracle.rendering_loss(g["input"], g["target"], g["scenes"])
+    assert_loss_close(loss.item(), ref_l, name + " vs oracle")
+    assert_loss_close(loss.item(), g["loss"], name + " vs reference", rtol=2e-6)
+    assert_grad_close(_np(grad), ref_g, name + " grad vs oracle")
+    assert_grad_close(_np(grad), g["grad_input"], name + " grad vs reference")
+    loss_fwd, none = native.rendering_loss(_t(g["input"], dev), _t(g["target"], dev), _t(g["scenes"], dev), want_grad=False)
+    assert none is None and loss_fwd.item() == loss.item()
+
+
+def test_rendering_loss_module_reproduces_reference_with_same_seed(dev, golden):
+    """end to end through RenderingLoss.forward: same torch seed -> same scenes -> same loss"""
+    from svbrdf_estimation_amd import losses, renderers
+    g = golden("g3_loss_48.npz")
+    fn = losses.RenderingLoss(renderers.LocalRenderer())
+    x = _t(g["input"], dev).requires_grad_(True)
+    torch.manual_seed(int(g["rng_seed"]))
+    loss = fn(x, _t(g["target"], dev))
+    assert loss.dim() == 0
+    (2.0 * loss).backward()
+    assert_loss_close(loss.item(), g["loss"], "module loss", rtol=2e-6)
+    assert_grad_close(_np(x.grad) / 2.0, g["grad_input"], "module grad (upstream grad 2)")
+    # MixedLoss = 0.1 * L1 + rendering (losses.py:54-63)
+    x2 = _t(g["input"], dev).requires_grad_(True)
+    torch.manual_seed(int(g["rng_seed"]))
+    mixed = losses.MixedLoss(renderers.LocalRenderer())(x2, _t(g["target"], dev))
+    mixed.backward()
+    assert_loss_close(mixed.item(), g["mixed_loss"], "mixed", rtol=2e-6)
+    assert_grad_close(_np(x2.grad), g["mixed_grad"], "mixed grad")
+    l1 = losses.SVBRDFL1Loss()(_t(g["input"], dev), _t(g["target"], dev))
+    assert_loss_close(l1.item(), g["l1_loss"], "l1", rtol=2e-6)
+
+
+def test_rendering_loss_custom_scene_counts_and_target_grad(dev, oracle, golden):
+    from svbrdf_estimation_amd import losses, renderers
+    g = golden("g3_loss_7_s5.npz")
+    fn = losses.RenderingLoss(renderers.LocalRenderer())
+    fn.random_configuration_count, fn.specular_configuration_count = int(g["n_random"]), int(g["n_specular"])
+    x = _t(g["input"], dev).requires_grad_(True)
+    t = _t(g["target"], dev).requires_grad_(True)
+    torch.manual_seed(int(g["rng_seed"]))
+    loss = fn(x, t)
+    loss.backward()
+    assert_loss_close(loss.item(), g["loss"], "s5 loss", rtol=2e-6)
+    assert_grad_close(_np(x.grad), g["grad_input"], "s5 grad")
+    _, gt = oracle.rendering_loss(g["target"], g["input"], g["scenes"])
+    assert_grad_close(_np(t.grad), gt, "target grad (roles swapped)")
+
+
+def test_full_size_properties_config2(dev, native, oracle):
+    """BASELINE config 2 size (B=8, 256x256, S=9): size-independent properties + a sampled
+    oracle comparison (the oracle on the full tensor would take too long for a unit test)."""
+    from svbrdf_estimation_amd import losses, renderers
+    B, H = 8, 256
+    inp, tgt = synth.make_maps(61, B, H), synth.make_maps(62, B, H)
+    fn = losses.RenderingLoss(renderers.LocalRenderer())
+    torch.manual_seed(2024)
+    table = fn.sample_scene_table(B).numpy()
+    d_in, d_tg, d_sc = _t(inp, dev), _t(tgt, dev), _t(table, dev)
+    loss, grad = native.rendering_loss(d_in, d_tg, d_sc)
+    # (1) identical input and target: loss exactly 0, gradient exactly 0 (sign(0) = 0)
+    l0, g0 = native.rendering_loss(d_in, d_in.clone(), d_sc)
+    assert l0.item() == 0.0 and not g0.any().item()
+    # (2) symmetry of |log a - log b| in the two arguments
+    ls, _ = native.rendering_loss(d_tg, d_in, d_sc)
+    assert_loss_close(ls.item(), loss.item(), "symmetry", rtol=1e-6)
+    # (3) bitwise run-to-run determinism
+    l2, g2 = native.rendering_loss(d_in, d_tg, d_sc)
+    assert l2.item() == loss.item() and torch.equal(g2, grad)
+    # (4) the loss of the batch is the mean of the per-item losses (what data-parallel sharding relies on)
+    per_item = [native.rendering_loss(d_in[b:b + 1], d_tg[b:b + 1], d_sc[b:b + 1])[0].item() for b in range(B)]
+    assert_loss_close(np.mean(per_item), loss.item(), "mean of shards", rtol=1e-6)
+    # (5) the fused kernel agrees with the separate K1 renderings pushed through torch's log/L1
+    ri, rt = native.render_fwd(d_in, d_sc), native.render_fwd(d_tg, d_sc)
+    l_sep = (torch.log(ri.double() + 0.1) - torch.log(rt.double() + 0.1)).abs().mean()
+    assert_loss_close(loss.item(), l_sep.item(), "fused vs K1+torch", rtol=2e-6)
+    # (6) and K2 applied to the L1 cotangent reproduces the fused gradient
+    cot = (torch.sign(torch.log(ri + 0.1) - torch.log(rt + 0.1)) / (ri + 0.1) / ri.numel())
+    assert_grad_close(_np(native.render_bwd(d_in, d_sc, cot)), _np(grad), "fused grad vs K2")
+    # (7) oracle on two batch items
+    for b in (0, B - 1):
+        lo, go = oracle.rendering_loss(inp[b:b + 1], tgt[b:b + 1], table[b:b + 1])
+        assert_loss_close(per_item[b], lo, "item %d vs oracle" % b)
+        assert_grad_close(_np(grad[b:b + 1]) * B, go, "item %d grad vs oracle" % b)
+
+
+# ---------------------------------------------------------------- plugin interface (renderers.py:67)
+
+def test_local_renderer_interface(dev, oracle, golden):
+    from svbrdf_estimation_amd import environment as env
+    from svbrdf_estimation_amd import renderers
+    g = golden("g4_batched_one_scene.npz")
+    R = renderers.LocalRenderer()
+    sc = env.Scene(env.Camera(torch.tensor(g["scene"][0:3])),
+                   env.Light(torch.tensor(g["scene"][3:6]), torch.tensor(g["scene"][6:9])))
+    x = _t(g["maps"], dev).requires_grad_(True)
+    out = R.render(sc, x)                       # 4-D input, one scene for the whole batch
+    assert tuple(out.shape) == (3, 3, 16, 16)
+    out.backward(_t(g["cot"], dev))
+    scn = np.repeat(g["scene"][None, None], 3, 0)
+    assert_render_vs_reference(_np(out), g["out"], oracle.render_fwd(g["maps"], scn, f64=True)[:, 0], "batched")
+    assert_grad_close(_np(x.grad), g["grad"], "batched grad")
+    out3 = R.render(sc, _t(g["maps"][0], dev))  # 3-D input -> [1,3,H,W]
+    assert tuple(out3.shape) == tuple(g["out3_shape"])
+    assert torch.equal(out3[0], out[0].detach())
+    # list / ndarray positions (losses.py callers) and a non-contiguous view
+    sc2 = env.Scene(env.Camera(list(g["scene"][0:3])), env.Light(np.asarray(g["scene"][3:6]), list(g["scene"][6:9])))
+    wide = torch.zeros(3, 12, 16, 32, device=dev)
+    wide[..., ::2] = _t(g["maps"], dev)
+    assert torch.equal(R.render(sc2, wide[..., ::2]), out.detach())
+    with pytest.raises(Exception):
+        R.render(sc, torch.zeros(12, 8, 8))                     # CPU tensor: fail loudly, no fallback
+    with pytest.raises(ValueError):
+        R.render(sc, torch.zeros(12, 8, 4, device=dev))         # H != W
+    with pytest.raises(TypeError):
+        R.render(sc, torch.zeros(12, 8, 8, device=dev, dtype=torch.float64))
+    many = R.render_many(torch.from_numpy(np.repeat(g["scene"][None], 2, 0)), _t(g["maps"], dev))
+    assert tuple(many.shape) == (3, 2, 3, 16, 16) and torch.equal(many[:, 1], out.detach())
+
+
+def test_plugin_path_with_foreign_renderer(dev):
+    """RenderingLoss keeps the duck-typed plugin protocol for any other renderer object"""
+    from svbrdf_estimation_amd import losses
+
+    class Flat:
+        def render(self, scene, svbrdf):
+            return svbrdf[3:6].unsqueeze(0) * float(scene.light.color[0])
+
+    x = torch.rand(2, 12, 8, 8, device=dev, requires_grad=True)
+    t = torch.rand(2, 12, 8, 8, device=dev)
+    torch.manual_seed(0)
+    loss = losses.RenderingLoss(Flat())(x, t)
+    loss.backward()
+    assert loss.item() > 0 and x.grad[:, 3:6].abs().sum().item() > 0 and not x.grad[:, 0:3].any().item()
+
+
+def test_optimisation_through_the_loss_decreases(dev):
+    """the notebooks' experiment (website.ipynb:300-337): optimise raw maps through the loss"""
+    from svbrdf_estimation_amd import losses, renderers
+    tgt = _t(synth.make_maps(71, 1, 32), dev)
+    x = _t(synth.make_maps(72, 1, 32), dev).requires_grad_(True)
+    fn = losses.RenderingLoss(renderers.LocalRenderer())
+    opt = torch.optim.Adam([x], lr=0.02)
+    torch.manual_seed(3)
+    table = fn.sample_scene_table(1).to(dev)
+    first = last = None
+    for _ in range(60):
+        opt.zero_grad()
+        loss = losses._FusedRenderingLoss.apply(x, tgt, table, 0.1)
+        loss.backward()
+        opt.step()
+        first = loss.item() if first is None else first
+        last = loss.item()
+    assert last < 0.6 * first
