@@ -61,36 +61,51 @@ def synthetic_maps(gen, B, H):
     return torch.cat((n, d, r, s), dim=1).contiguous()
 
 
-def cpu_baseline(args, inp, tgt, table):
-    """Eager-PyTorch port of the reference's algorithm on the host cores (bounded sample)."""
+def _time_eager(threads, inp, tgt, table, budget_s, max_patches=64):
     from oracle import eager_torch
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    nb = min(2, inp.shape[0])
-    xi = inp[:nb].clone().requires_grad_(True)
-    eager_torch.rendering_loss(xi, tgt[:nb], table[:nb]).backward()      # warm-up
+    torch.set_num_threads(threads)
+    xi = inp[:1].clone().requires_grad_(True)
+    eager_torch.rendering_loss(xi, tgt[:1], table[:1]).backward()      # warm-up, untimed
     done, t0 = 0, time.perf_counter()
     while True:
-        xi = inp[:nb].clone().requires_grad_(True)
-        eager_torch.rendering_loss(xi, tgt[:nb], table[:nb]).backward()
-        done += nb
+        b = done % inp.shape[0]
+        xi = inp[b:b + 1].clone().requires_grad_(True)
+        eager_torch.rendering_loss(xi, tgt[b:b + 1], table[b:b + 1]).backward()
+        done += 1
         el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or done >= 64:
-            break
-    res = {"value": done / el, "unit": "patches/s", "cores": cores, "kind": "port",
-           "sample": "%d patches of %dx%d, S=%d, fwd+bwd, eager PyTorch (oracle/eager_torch.py), %.1f s"
-                     % (done, args.size, args.size, table.shape[1], el)}
+        if el >= budget_s or done >= max_patches:
+            return done / el, done, el
+
+
+def cpu_baseline(args, inp, tgt, table):
+    """Eager-PyTorch port of the reference's algorithm on the host cores (bounded sample).
+    Eager 256x256 elementwise ops do not scale to hundreds of threads, so a few thread
+    counts are tried briefly and the fastest is the reported baseline (cores = threads used)."""
+    ncpu = os.cpu_count() or 1
+    cands = sorted({min(ncpu, c) for c in (4, 8, 16, 32)})
+    probe = {}
+    for c in cands:
+        probe[c] = _time_eager(c, inp, tgt, table, budget_s=1.5, max_patches=4)[0]
+        print("[bench] cpu probe threads=%d: %.2f patches/s" % (c, probe[c]), file=sys.stderr, flush=True)
+    best = max(probe, key=probe.get)
+    rate, done, el = _time_eager(best, inp, tgt, table, budget_s=args.cpu_seconds)
+    one, _, _ = _time_eager(1, inp, tgt, table, budget_s=3.0, max_patches=4)
+    res = {"value": rate, "unit": "patches/s", "cores": best, "kind": "port",
+           "sample": "%d patches of %dx%d, S=%d, fwd+bwd, eager PyTorch restatement (oracle/eager_torch.py), "
+                     "%.1f s, best of threads %s on a %d-cpu host" % (done, args.size, args.size, table.shape[1], el,
+                                                                     cands, ncpu),
+           "one_thread_patches_per_s": one}
     try:   # the plain-C oracle on all cores, for orientation
         from oracle import c_oracle
-        c_oracle.set_threads(cores)
-        a, b, c = inp[:nb].numpy(), tgt[:nb].numpy(), table[:nb].numpy()
+        c_oracle.set_threads(ncpu)
+        a, b, c = inp[:2].numpy(), tgt[:2].numpy(), table[:2].numpy()
         c_oracle.rendering_loss(a, b, c)
         t0 = time.perf_counter()
         reps = 0
         while time.perf_counter() - t0 < 3.0:
             c_oracle.rendering_loss(a, b, c)
             reps += 1
-        res["c_oracle_patches_per_s"] = reps * nb / (time.perf_counter() - t0)
+        res["c_oracle_patches_per_s"] = reps * 2 / (time.perf_counter() - t0)
         res["c_oracle_threads"] = c_oracle.max_threads()
     except Exception as e:  # pragma: no cover
         res["c_oracle_error"] = repr(e)

@@ -88,6 +88,15 @@ SVBRDF_API int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *ta
                                   void *workspace, size_t workspace_bytes,
                                   int B, int S, int H, int W, void *stream);
 
+/* Test aid: evaluates the kernels' shared-reciprocal division and Newton square root
+ * (the primitives that stand in for the reference's torch.div / torch.sqrt on the
+ * ill-conditioned coords -> NH path) on n pseudo-random operands -- denominators
+ * log-uniform in [lo, hi], numerators uniform in [-hi, hi] -- and ADDS the number of
+ * results that differ from the IEEE-correct `/` and sqrtf to counts_dev[0] (division)
+ * and counts_dev[1] (sqrt).  counts_dev: two zero-initialised device uint64. */
+SVBRDF_API int svbrdf_debug_check_arith(unsigned long long n, unsigned seed, float lo, float hi,
+                                        unsigned long long *counts_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

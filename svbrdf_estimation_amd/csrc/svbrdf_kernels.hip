@@ -41,7 +41,7 @@ constexpr float kMinRough = 0.001f;    // renderers.py:87
 constexpr float kMinDen = 0.001f;      // renderers.py:26
 
 // ------------------------------------------------------------------------------------------
-// per-pixel device code
+// arithmetic primitives
 // ------------------------------------------------------------------------------------------
 
 // torch.sum(a*b, dim=-3): three separately rounded products, summed (p0+p1)+p2
@@ -51,52 +51,137 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
     return (p0 + p1) + p2;
 }
 
-struct Geom {
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32, 1 ULP
+__device__ __forceinline__ float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }    // v_rsq_f32, 1 ULP
+
+// Correctly rounded a/b for several numerators over ONE denominator: the reciprocal is
+// refined once (v_rcp + 2 FMA, Newton) and shared; each quotient then costs a multiply and
+// two exact-residual FMA corrections (Markstein).  Same result as the compiler's IEEE
+// division sequence (v_div_scale/v_div_fmas/v_div_fixup, ~11 instructions per quotient) for
+// operands away from the overflow/denormal range, which holds here: |a| <= ~1e3 and
+// 1e-3 <~ b <~ 1e3 (lengths of camera/light offsets).  svbrdf_debug_check_arith() measures
+// the agreement with the IEEE `/` on the device.
+struct Recip {
+    float b, y;
+};
+__device__ __forceinline__ Recip make_recip(float b)
+{
+    const float y0 = rcp_(b);
+    const float e = fma_(-b, y0, 1.0f);
+    return Recip{b, fma_(e, y0, y0)};
+}
+__device__ __forceinline__ float div_rn(float a, const Recip &r)
+{
+    float q = a * r.y;
+    float e = fma_(-r.b, q, a);
+    q = fma_(e, r.y, q);
+    e = fma_(-r.b, q, a);
+    return fma_(e, r.y, q);
+}
+
+// Correctly rounded sqrt for x in the normal range (Markstein: rsq seed, one coupled
+// Newton step on (g ~ sqrt x, h ~ 1/(2 sqrt x)), final exact-residual correction).
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    const float y = rsq_(x);
+    float g = x * y;
+    float h = 0.5f * y;
+    const float r = fma_(-h, g, 0.5f);
+    g = fma_(g, r, g);
+    h = fma_(h, r, h);
+    const float d = fma_(-g, g, x);
+    return fma_(d, h, g);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-pixel device code
+// ------------------------------------------------------------------------------------------
+
+struct Geom {           // map-independent, shared by input and target and by the 3 channels
     float wox, woy, woz;
     float wix, wiy, wiz;
     float hx, hy, hz;
-    float fall;   // 1 / (sqrt(|L|^2))^2      renderers.py:99
-    float p;      // (1 - VH)^5               renderers.py:32
+    float p;            // (1 - VH)^5               renderers.py:32
+    float E[3];         // light_color * falloff     renderers.py:98-100
 };
 
-// map-independent part of render(): renderers.py:73-82, 91-93, 45, 49, 99.
-// `sc` is wave-uniform (scalar loads).
-__device__ __forceinline__ Geom geometry(const float *__restrict__ sc, float x, float y)
+// renderers.py:73-82, 91-93, 45, 49, 99.  `sc` (9 floats) is wave-uniform.  Everything up to
+// h reproduces the reference's rounding sequence exactly (see the header of this file).
+__device__ __forceinline__ Geom geometry(const float sc[9], float x, float y)
 {
     Geom g;
     const float rcx = sc[0] - x, rcy = sc[1] - y, rcz = sc[2];   // z of the patch is 0
     const float rlx = sc[3] - x, rly = sc[4] - y, rlz = sc[5];
-    const float lc = sqrtf(dot3(rcx, rcy, rcz, rcx, rcy, rcz));
-    const float d2 = dot3(rlx, rly, rlz, rlx, rly, rlz);
-    const float ll = sqrtf(d2);
-    g.wox = rcx / lc; g.woy = rcy / lc; g.woz = rcz / lc;
-    g.wix = rlx / ll; g.wiy = rly / ll; g.wiz = rlz / ll;
+    const float lc = sqrt_rn(dot3(rcx, rcy, rcz, rcx, rcy, rcz));
+    const float ll = sqrt_rn(dot3(rlx, rly, rlz, rlx, rly, rlz));
+    const Recip ic = make_recip(lc), il = make_recip(ll);
+    g.wox = div_rn(rcx, ic); g.woy = div_rn(rcy, ic); g.woz = div_rn(rcz, ic);
+    g.wix = div_rn(rlx, il); g.wiy = div_rn(rly, il); g.wiz = div_rn(rlz, il);
     const float sx = (g.wix + g.wox) * 0.5f, sy = (g.wiy + g.woy) * 0.5f, sz = (g.wiz + g.woz) * 0.5f;
-    const float lh = sqrtf(dot3(sx, sy, sz, sx, sy, sz));
-    g.hx = sx / lh; g.hy = sy / lh; g.hz = sz / lh;
+    const Recip ih = make_recip(sqrt_rn(dot3(sx, sy, sz, sx, sy, sz)));
+    g.hx = div_rn(sx, ih); g.hy = div_rn(sy, ih); g.hz = div_rn(sz, ih);
+    // from here on the computation is well conditioned: 1-ULP primitives are enough
     const float VH = fmaxf(dot3(g.wox, g.woy, g.woz, g.hx, g.hy, g.hz), kMinDot);
     const float t = 1.0f - VH;
     const float t2 = t * t;
     g.p = (t2 * t2) * t;
-    g.fall = 1.0f / (ll * ll);
+    const float fall = rcp_(ll * ll);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g.E[k] = sc[6 + k] * fall;
     return g;
 }
 
-struct Maps {           // one pixel of a [12,H,W] SVBRDF
+struct Maps {           // one pixel of a [12,H,W] SVBRDF as stored
     float n[3], d[3], r[3], s[3];
 };
 
-struct Ctx {            // forward values the adjoint needs
-    float nh_raw, vn_raw, ln_raw;
-    float NH, VN, LN, LNp, uV, uL, q4;
-    float r[3], A[3], F[3], G1V[3], G1L[3], wV[3], wL[3], D[3], den[3], den_raw[3];
-    float spec[3], f[3], E[3];
+struct Grad {           // d/d(maps) of one pixel
+    float n[3], d[3], r[3], s[3];
 };
 
-// map-dependent part of render(): renderers.py:43-65, 87, 95-100
+struct MapK {           // scene-independent per-pixel constants, hoisted out of the scene loop
+    float n[3];
+    float A[3];         // r^4 with r = max(r_hat, 1e-3)        renderers.py:87, 23-24
+    float s[3], oms[3]; // specular, 1 - specular
+    float dpi[3];       // diffuse / pi
+    float r4m[3];       // dA/dr_hat = 4 r^3, 0 where r_hat < 1e-3 (clamp mask)
+};
+
+template <bool BWD>
+__device__ __forceinline__ MapK prepare(const Maps &m)
+{
+    MapK k;
+    constexpr float inv_pi = 1.0f / kPi;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float r = fmaxf(m.r[c], kMinRough);
+        const float a = r * r;
+        k.n[c] = m.n[c];
+        k.A[c] = a * a;
+        k.s[c] = m.s[c];
+        k.oms[c] = 1.0f - m.s[c];
+        k.dpi[c] = m.d[c] * inv_pi;
+        if (BWD) k.r4m[c] = (m.r[c] >= kMinRough) ? 4.0f * (a * r) : 0.0f;
+    }
+    return k;
+}
+
+struct Ctx {            // forward values the adjoint needs
+    float nh_raw, vn_raw, ln_raw;
+    float NH, NH2, uV, uL, iVN, iLN, iq, LNp;
+    float F[3], Gp[3], D[3], spec[3], f[3];
+    float rV[3], rL[3], iwV[3], iwL[3];
+    float ipd2[3], pd[3];
+    bool den_on[3];
+};
+
+// map-dependent part of render(): renderers.py:43-65, 95-100.
+// The three clamped dot products and 1-NH^2 follow the reference's rounding exactly; the
+// rest uses v_rcp/v_rsq (1 ULP each) -- the result differs from the op-by-op evaluation
+// by a few 1e-7 relative, 50x inside the parity budget.
 template <bool KEEP>
-__device__ __forceinline__ void shade(const Geom &g, const float *__restrict__ col, const Maps &m,
-                                      float rad[3], Ctx &c)
+__device__ __forceinline__ void shade(const Geom &g, const MapK &m, float rad[3], Ctx &c)
 {
     const float nh_raw = dot3(m.n[0], m.n[1], m.n[2], g.hx, g.hy, g.hz);
     const float vn_raw = dot3(g.wox, g.woy, g.woz, m.n[0], m.n[1], m.n[2]);
@@ -104,86 +189,89 @@ __device__ __forceinline__ void shade(const Geom &g, const float *__restrict__ c
     const float NH = fmaxf(nh_raw, kMinDot), VN = fmaxf(vn_raw, kMinDot), LN = fmaxf(ln_raw, kMinDot);
     const float LNp = fmaxf(ln_raw, 0.0f);
     const float NH2 = NH * NH, VN2 = VN * VN, LN2 = LN * LN;
-    const float oV = 1.0f - VN2, oL = 1.0f - LN2;
-    const float iN = (1.0f - NH2) / NH2;
-    const float q4 = (4.0f * VN) * LN;
+    const float iN = (1.0f - NH2) * rcp_(NH2);            // (1 - NH^2) / NH^2
+    const float iVN = rcp_(VN), iLN = rcp_(LN);
+    const float uV = (1.0f - VN2) * (iVN * iVN);          // (1 - VN^2) / VN^2
+    const float uL = (1.0f - LN2) * (iLN * iLN);
+    const float iq = iVN * iLN;                           // 4/(4 VN LN): the 4 cancels against G1V*G1L
     if (KEEP) {
         c.nh_raw = nh_raw; c.vn_raw = vn_raw; c.ln_raw = ln_raw;
-        c.NH = NH; c.VN = VN; c.LN = LN; c.LNp = LNp; c.q4 = q4;
-        c.uV = oV / VN2; c.uL = oL / LN2;
+        c.NH = NH; c.NH2 = NH2; c.uV = uV; c.uL = uL; c.iVN = iVN; c.iLN = iLN; c.iq = iq; c.LNp = LNp;
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float r = fmaxf(m.r[k], kMinRough);
-        const float a = r * r;
-        const float A = a * a;
-        const float F = m.s[k] + (1.0f - m.s[k]) * g.p;
-        const float wV = sqrtf(1.0f + (A * oV) / VN2);
-        const float wL = sqrtf(1.0f + (A * oL) / LN2);
-        const float G1V = 2.0f / (1.0f + wV);
-        const float G1L = 2.0f / (1.0f + wL);
+        const float A = m.A[k];
+        const float F = fma_(m.oms[k], g.p, m.s[k]);                  // Schlick
+        const float xV = fma_(A, uV, 1.0f), xL = fma_(A, uL, 1.0f);   // 1 + A (1-XN^2)/XN^2
+        const float iwV = rsq_(xV), iwL = rsq_(xL);
+        const float rV = rcp_(fma_(xV, iwV, 1.0f));                   // 1/(1 + sqrt(xV)) = G1V/2
+        const float rL = rcp_(fma_(xL, iwL, 1.0f));
+        const float Gp = rV * rL;                                     // G/4
         const float den_raw = NH2 * (A + iN);
         const float den = fmaxf(den_raw, kMinDen);
-        const float D = A / (kPi * (den * den));
-        const float spec = ((F * (G1V * G1L)) * D) / q4;
-        const float f = (((1.0f - F) * m.d[k]) / kPi) + spec;
-        const float E = col[k] * g.fall;
-        rad[k] = (f * E) * LNp;
+        const float pd = kPi * den;
+        const float ipd2 = rcp_(pd * den);
+        const float D = A * ipd2;                                     // GGX
+        const float spec = ((F * Gp) * D) * iq;
+        const float f = fma_(1.0f - F, m.dpi[k], spec);
+        rad[k] = f * (g.E[k] * LNp);
         if (KEEP) {
-            c.r[k] = r; c.A[k] = A; c.F[k] = F; c.wV[k] = wV; c.wL[k] = wL;
-            c.G1V[k] = G1V; c.G1L[k] = G1L; c.den_raw[k] = den_raw; c.den[k] = den;
-            c.D[k] = D; c.spec[k] = spec; c.f[k] = f; c.E[k] = E;
+            c.F[k] = F; c.Gp[k] = Gp; c.D[k] = D; c.spec[k] = spec; c.f[k] = f;
+            c.rV[k] = rV; c.rL[k] = rL; c.iwV[k] = iwV; c.iwL[k] = iwL;
+            c.ipd2[k] = ipd2; c.pd[k] = pd; c.den_on[k] = den_raw >= kMinDen;
         }
     }
 }
 
-struct Grad {           // d/d(maps) of one pixel
-    float n[3], d[3], r[3], s[3];
-};
-
 // adjoint of shade() with PyTorch's sub-gradient conventions: clamp(min=m) passes the
 // gradient iff x >= m (inclusive); xi() has zero gradient (renderers.py:15-16).
-__device__ __forceinline__ void shade_bwd(const Geom &g, const Ctx &c, const Maps &m,
+__device__ __forceinline__ void shade_bwd(const Geom &g, const MapK &m, const Ctx &c,
                                           const float g_rad[3], Grad &acc)
 {
-    float g_LNp = 0.0f, g_NH = 0.0f, g_VN = 0.0f, g_LN = 0.0f;
-    const float NH2 = c.NH * c.NH;
-    const float inv_q4 = 1.0f / c.q4;
-    const float inv_VN = 1.0f / c.VN, inv_LN = 1.0f / c.LN;
-    const float inv_VN3 = (inv_VN * inv_VN) * inv_VN, inv_LN3 = (inv_LN * inv_LN) * inv_LN;
-    const float inv_pi = 1.0f / kPi;
+    float g_LNp = 0.0f, sNH = 0.0f, sV = 0.0f, sL = 0.0f, sSp = 0.0f;
+    constexpr float inv_pi = 1.0f / kPi;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float g_f = (g_rad[k] * c.E[k]) * c.LNp;
-        const float G = c.G1V[k] * c.G1L[k];
-        const float gfq = g_f * inv_q4;
-        const float g_F = g_f * ((G * c.D[k]) * inv_q4 - m.d[k] * inv_pi);
-        const float g_G = gfq * (c.F[k] * c.D[k]);
-        const float g_D = gfq * (c.F[k] * G);
-        const float g_sp = g_f * c.spec[k];
-        const float g_tV = -(g_G * c.G1L[k]) * (c.G1V[k] * c.G1V[k]) / (4.0f * c.wV[k]);
-        const float g_tL = -(g_G * c.G1V[k]) * (c.G1L[k] * c.G1L[k]) / (4.0f * c.wL[k]);
-        const float inv_pd2 = 1.0f / (kPi * (c.den[k] * c.den[k]));
-        float g_A = (g_tV * c.uV + g_tL * c.uL) + g_D * inv_pd2;
-        const float g_den = (c.den_raw[k] >= kMinDen) ? (-2.0f * g_D) * (c.A[k] * inv_pd2) / c.den[k] : 0.0f;
-        g_LNp += (g_rad[k] * c.f[k]) * c.E[k];
-        acc.d[k] += g_f * ((1.0f - c.F[k]) * inv_pi);
-        acc.s[k] += g_F * (1.0f - g.p);
-        g_VN += (g_tV * (-2.0f * c.A[k])) * inv_VN3 - g_sp * inv_VN;
-        g_LN += (g_tL * (-2.0f * c.A[k])) * inv_LN3 - g_sp * inv_LN;
-        g_A += g_den * NH2;
-        g_NH += (g_den * (c.A[k] - 1.0f)) * (2.0f * c.NH);
-        if (m.r[k] >= kMinRough)
-            acc.r[k] += (g_A * 4.0f) * ((c.r[k] * c.r[k]) * c.r[k]);
+        const float gE = g_rad[k] * g.E[k];
+        const float g_f = gE * c.LNp;
+        g_LNp = fma_(gE, c.f[k], g_LNp);
+        const float gfq = g_f * c.iq;
+        const float GD = c.Gp[k] * c.D[k];
+        const float g_F = fma_(gfq, GD, -(g_f * m.dpi[k]));
+        acc.s[k] = fma_(g_F, 1.0f - g.p, acc.s[k]);
+        acc.d[k] = fma_(g_f * (1.0f - c.F[k]), inv_pi, acc.d[k]);
+        const float gfqF = gfq * c.F[k];
+        const float g_Gp = gfqF * c.D[k];          // d/dGp
+        const float g_D = gfqF * c.Gp[k];
+        sSp = fma_(g_f, c.spec[k], sSp);
+        // Gp = rV*rL, rX = 1/(1+wX), wX = sqrt(xX), xX = 1 + A*uX:  dGp/dxV = -Gp*rV/(2 wV)
+        const float gG = g_Gp * c.Gp[k];
+        const float g_xV = (-0.5f * gG) * (c.rV[k] * c.iwV[k]);
+        const float g_xL = (-0.5f * gG) * (c.rL[k] * c.iwL[k]);
+        float g_A = fma_(g_xV, c.uV, g_xL * c.uL);
+        sV = fma_(g_xV, m.A[k], sV);               // d xV / d uV = A
+        sL = fma_(g_xL, m.A[k], sL);
+        // D = A/(pi den^2)
+        g_A = fma_(g_D, c.ipd2[k], g_A);
+        const float iden = c.ipd2[k] * c.pd[k];    // 1/den
+        const float g_den = c.den_on[k] ? (-2.0f * g_D) * (c.D[k] * iden) : 0.0f;
+        // den_raw = m*(A + (1-m)/m), m = NH^2:  d/dA = m, d/dm = A - 1
+        g_A = fma_(g_den, c.NH2, g_A);
+        sNH = fma_(g_den, m.A[k] - 1.0f, sNH);
+        acc.r[k] = fma_(g_A, m.r4m[k], acc.r[k]);
     }
+    // uX = 1/XN^2 - 1: d uX/d XN = -2/XN^3 ; spec ~ 1/(VN LN)
+    float g_NH = (sNH * 2.0f) * c.NH;
+    float g_VN = -c.iVN * fma_(2.0f * sV, c.iVN * c.iVN, sSp);
+    float g_LN = -c.iLN * fma_(2.0f * sL, c.iLN * c.iLN, sSp);
     if (!(c.nh_raw >= kMinDot)) g_NH = 0.0f;
     if (!(c.vn_raw >= kMinDot)) g_VN = 0.0f;
     if (!(c.ln_raw >= kMinDot)) g_LN = 0.0f;
     if (!(c.ln_raw >= 0.0f)) g_LNp = 0.0f;
     const float gl = g_LN + g_LNp;
-    acc.n[0] += (g_NH * g.hx + g_VN * g.wox) + gl * g.wix;
-    acc.n[1] += (g_NH * g.hy + g_VN * g.woy) + gl * g.wiy;
-    acc.n[2] += (g_NH * g.hz + g_VN * g.woz) + gl * g.wiz;
+    acc.n[0] = fma_(g_NH, g.hx, fma_(g_VN, g.wox, fma_(gl, g.wix, acc.n[0])));
+    acc.n[1] = fma_(g_NH, g.hy, fma_(g_VN, g.woy, fma_(gl, g.wiy, acc.n[1])));
+    acc.n[2] = fma_(g_NH, g.hz, fma_(g_VN, g.woz, fma_(gl, g.wiz, acc.n[2])));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -276,6 +364,14 @@ __device__ __forceinline__ void pixel_coords(const float *__restrict__ xrow, siz
     y = -xrow[i];
 }
 
+// the nine scalars of one render (camera xyz | light xyz | light rgb); the pointer is
+// wave-uniform, so these become scalar loads into SGPRs
+__device__ __forceinline__ void load_scene(const float *__restrict__ p, float sc[9])
+{
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sc[i] = p[i];
+}
+
 // ------------------------------------------------------------------------------------------
 // K1: render forward.  grid = (ceil(H*W / (256*VEC)), B); S renders per map in one pass.
 // ------------------------------------------------------------------------------------------
@@ -289,19 +385,26 @@ __global__ __launch_bounds__(kThreads) void k_render_fwd(const float *__restrict
     const size_t pix = ((size_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
     const int b = blockIdx.y;
     if (pix >= plane) return;
-    Maps m[VEC];
-    load_maps<VEC>(maps + (size_t)b * 12 * plane, plane, pix, m);
+    MapK mk[VEC];
+    {
+        Maps m[VEC];
+        load_maps<VEC>(maps + (size_t)b * 12 * plane, plane, pix, m);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) mk[v] = prepare<false>(m[v]);
+    }
     float x[VEC], y;
     pixel_coords<VEC>(xrow, pix, W, x, y);
-    const float *__restrict__ sc = scenes + (size_t)b * S * 9;
+    const float *__restrict__ scp = scenes + (size_t)b * S * 9;
     float *__restrict__ o = out + (size_t)b * S * 3 * plane + pix;
-    for (int s = 0; s < S; ++s, sc += 9, o += 3 * plane) {
+    for (int s = 0; s < S; ++s, scp += 9, o += 3 * plane) {
+        float sc[9];
+        load_scene(scp, sc);
         float rad[VEC][3];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const Geom g = geometry(sc, x[v], y);
             Ctx unused;
-            shade<false>(g, sc + 6, m[v], rad[v], unused);
+            shade<false>(g, mk[v], rad[v], unused);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -328,16 +431,23 @@ __global__ __launch_bounds__(kThreads) void k_render_bwd(const float *__restrict
     const size_t pix = ((size_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
     const int b = blockIdx.y;
     if (pix >= plane) return;
-    Maps m[VEC];
-    load_maps<VEC>(maps + (size_t)b * 12 * plane, plane, pix, m);
+    MapK mk[VEC];
+    {
+        Maps m[VEC];
+        load_maps<VEC>(maps + (size_t)b * 12 * plane, plane, pix, m);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) mk[v] = prepare<true>(m[v]);
+    }
     float x[VEC], y;
     pixel_coords<VEC>(xrow, pix, W, x, y);
     Grad acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) zero_grad(acc[v]);
-    const float *__restrict__ sc = scenes + (size_t)b * S * 9;
+    const float *__restrict__ scp = scenes + (size_t)b * S * 9;
     const float *__restrict__ go = grad_out + (size_t)b * S * 3 * plane + pix;
-    for (int s = 0; s < S; ++s, sc += 9, go += 3 * plane) {
+    for (int s = 0; s < S; ++s, scp += 9, go += 3 * plane) {
+        float sc[9];
+        load_scene(scp, sc);
         float gr[3][VEC];
 #pragma unroll
         for (int k = 0; k < 3; ++k) load_vec<VEC>(go + (size_t)k * plane, gr[k]);
@@ -346,9 +456,9 @@ __global__ __launch_bounds__(kThreads) void k_render_bwd(const float *__restrict
             const Geom g = geometry(sc, x[v], y);
             Ctx c;
             float rad[3];
-            shade<true>(g, sc + 6, m[v], rad, c);
+            shade<true>(g, mk[v], rad, c);
             const float g_rad[3] = {gr[0][v], gr[1][v], gr[2][v]};
-            shade_bwd(g, c, m[v], g_rad, acc[v]);
+            shade_bwd(g, mk[v], c, g_rad, acc[v]);
         }
     }
     store_grads<VEC>(grad_maps + (size_t)b * 12 * plane, plane, pix, acc);
@@ -378,38 +488,55 @@ __global__ __launch_bounds__(kThreads) void k_rendering_loss(const float *__rest
                                                              float *__restrict__ partials, int S, int H, int W)
 {
     __shared__ float wave_part[kThreads / 64];
+    constexpr float kLn2 = 0.693147180559945309417f;
     const size_t plane = (size_t)H * W;
     const size_t pix = ((size_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
     const int b = blockIdx.y;
     const bool active = pix < plane;
     float lsum = 0.0f;
     if (active) {
-        Maps mi[VEC], mt[VEC];
-        load_maps<VEC>(input + (size_t)b * 12 * plane, plane, pix, mi);
-        load_maps<VEC>(target + (size_t)b * 12 * plane, plane, pix, mt);
+        MapK mi[VEC], mt[VEC];
+        {
+            Maps m[VEC];
+            load_maps<VEC>(input + (size_t)b * 12 * plane, plane, pix, m);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) mi[v] = prepare<WITH_GRAD>(m[v]);
+            load_maps<VEC>(target + (size_t)b * 12 * plane, plane, pix, m);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) mt[v] = prepare<false>(m[v]);
+        }
         float x[VEC], y;
         pixel_coords<VEC>(xrow, pix, W, x, y);
         Grad acc[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) zero_grad(acc[v]);
-        const float *__restrict__ sc = scenes + (size_t)b * S * 9;
-        for (int s = 0; s < S; ++s, sc += 9) {
+        const float *__restrict__ scp = scenes + (size_t)b * S * 9;
+        float sc[9], sc_next[9];
+        load_scene(scp, sc_next);
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sc[i] = sc_next[i];
+            // prefetch the next render's scalars (SGPRs) behind this iteration's arithmetic
+            scp += (s + 1 < S) ? 9 : 0;
+            load_scene(scp, sc_next);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 const Geom g = geometry(sc, x[v], y);
                 Ctx ci, ct;
                 float ri[3], rt[3], g_rad[3];
-                shade<WITH_GRAD>(g, sc + 6, mi[v], ri, ci);
-                shade<false>(g, sc + 6, mt[v], rt, ct);
+                shade<false>(g, mt[v], rt, ct);
+                shade<WITH_GRAD>(g, mi[v], ri, ci);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const float ai = ri[k] + eps, at = rt[k] + eps;   // losses.py:46-48
-                    const float delta = logf(ai) - logf(at);
-                    lsum += fabsf(delta);                              // losses.py:50 (L1)
-                    const float sg = (delta > 0.0f) ? inv_count : ((delta < 0.0f) ? -inv_count : 0.0f);
-                    g_rad[k] = sg / ai;
+                    // losses.py:46-50: |log(ri + eps) - log(rt + eps)|, v_log_f32 = log2
+                    const float ai = ri[k] + eps, at = rt[k] + eps;
+                    const float delta = kLn2 * (__builtin_amdgcn_logf(ai) - __builtin_amdgcn_logf(at));
+                    lsum += fabsf(delta);
+                    // d|delta|/d ri = sign(delta)/(N*ai), sign(0) = 0 as in torch
+                    const float sg = __builtin_amdgcn_fmed3f(delta * 1.0e30f, -1.0f, 1.0f);
+                    g_rad[k] = sg * (inv_count * rcp_(ai));
                 }
-                if (WITH_GRAD) shade_bwd(g, ci, mi[v], g_rad, acc[v]);
+                if (WITH_GRAD) shade_bwd(g, mi[v], ci, g_rad, acc[v]);
             }
         }
         if (WITH_GRAD) store_grads<VEC>(grad_input + (size_t)b * 12 * plane, plane, pix, acc);
@@ -423,6 +550,34 @@ __global__ __launch_bounds__(kThreads) void k_rendering_loss(const float *__rest
         for (int w = 0; w < kThreads / 64; ++w) t += wave_part[w];
         partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// arithmetic self-check: div_rn / sqrt_rn against the compiler's IEEE `/` and sqrtf
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned hash32(unsigned x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(kThreads) void k_check_arith(unsigned long long n, unsigned seed, float lo, float hi,
+                                                          unsigned long long *__restrict__ counts)
+{
+    unsigned long long bad_div = 0, bad_sqrt = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const unsigned h0 = hash32((unsigned)i * 2654435761U + seed), h1 = hash32(h0 ^ (unsigned)(i >> 32) ^ 0x9e3779b9U);
+        // denominators log-uniform in [lo, hi], numerators uniform in [-hi, hi] with random mantissas
+        const float u0 = (float)(h0 >> 8) * (1.0f / 16777216.0f), u1 = (float)(h1 >> 8) * (1.0f / 16777216.0f);
+        const float b = lo * exp2f(u0 * log2f(hi / lo));
+        const float a = (2.0f * u1 - 1.0f) * hi;
+        const Recip r = make_recip(b);
+        if (div_rn(a, r) != a / b) ++bad_div;
+        if (sqrt_rn(b) != sqrtf(b)) ++bad_sqrt;
+    }
+    if (bad_div) atomicAdd(&counts[0], bad_div);
+    if (bad_sqrt) atomicAdd(&counts[1], bad_sqrt);
 }
 
 // one workgroup: fixed-order fp64 sum of the per-workgroup partials -> mean
@@ -597,6 +752,16 @@ int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *target, const
     if (int e = launch_status("rendering_loss launch")) return e;
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), block, 0, st, partials, (int)(grid.x * grid.y), 1.0 / count, loss_out);
     return launch_status("loss_finalize launch");
+}
+
+int svbrdf_debug_check_arith(unsigned long long n, unsigned seed, float lo, float hi,
+                             unsigned long long *counts_dev, void *stream)
+{
+    if (!counts_dev) return fail(SVBRDF_ERR_NULL, "check_arith: null pointer");
+    if (!(lo > 0.0f) || !(hi > lo)) return fail(SVBRDF_ERR_DIMS, "check_arith: need 0 < lo < hi");
+    hipLaunchKernelGGL(k_check_arith, dim3(2048), dim3(kThreads), 0, static_cast<hipStream_t>(stream), n, seed, lo, hi,
+                       counts_dev);
+    return launch_status("check_arith launch");
 }
 
 }  // extern "C"
