@@ -88,6 +88,12 @@ SVBRDF_API int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *ta
                                   void *workspace, size_t workspace_bytes,
                                   int B, int S, int H, int W, void *stream);
 
+/* data[i] *= scale_dev[0] for i < n, on the device and without a host sync; when the
+ * scalar is exactly 1.0 the kernel exits without touching `data`.  Used by the autograd
+ * wrapper to apply the upstream gradient of the loss (the chain rule through
+ * RenderingLoss.forward's scalar output) to grad_input. */
+SVBRDF_API int svbrdf_scale_inplace(float *data, const float *scale_dev, size_t n, void *stream);
+
 /* Test aid: evaluates the kernels' shared-reciprocal division and Newton square root
  * (the primitives that stand in for the reference's torch.div / torch.sqrt on the
  * ill-conditioned coords -> NH path) on n pseudo-random operands -- denominators

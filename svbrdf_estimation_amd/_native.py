@@ -68,6 +68,8 @@ def _load():
         lib.svbrdf_rendering_loss_workspace_bytes.restype = ctypes.c_size_t
         lib.svbrdf_rendering_loss_fwd_bwd.argtypes = (
             [_fp, _fp, _fp, _fp, ctypes.c_float, _fp, _fp, _fp, ctypes.c_size_t] + [ctypes.c_int] * 4 + [_fp])
+        lib.svbrdf_scale_inplace.argtypes = [_fp, _fp, ctypes.c_size_t, _fp]
+        lib.svbrdf_scale_inplace.restype = ctypes.c_int
         for name in ("svbrdf_make_xrow", "svbrdf_render_fwd", "svbrdf_render_bwd", "svbrdf_rendering_loss_fwd_bwd"):
             getattr(lib, name).restype = ctypes.c_int
         v = lib.svbrdf_abi_version()
@@ -193,3 +195,15 @@ def rendering_loss(input, target, scenes, eps=0.1, want_grad=True):
             hook("end")
     _check(rc, "svbrdf_rendering_loss_fwd_bwd")
     return loss, grad
+
+
+def scale_inplace_(data, scale):
+    """data *= scale (a one-element device tensor) without a host sync; no-op kernel when scale == 1."""
+    _require_device_f32(data, "data")
+    _require_device_f32(scale, "scale")
+    if not data.is_contiguous() or scale.numel() != 1:
+        raise ValueError("scale_inplace_ needs a contiguous tensor and a one-element scale")
+    with torch.cuda.device(data.device):
+        _check(_load().svbrdf_scale_inplace(data.data_ptr(), scale.data_ptr(), data.numel(), _stream(data.device)),
+               "svbrdf_scale_inplace")
+    return data

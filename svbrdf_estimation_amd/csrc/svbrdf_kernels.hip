@@ -552,6 +552,17 @@ __global__ __launch_bounds__(kThreads) void k_rendering_loss(const float *__rest
     }
 }
 
+// data[i] *= *scale, skipped entirely (no memory traffic) when *scale == 1: lets the autograd
+// wrapper apply an upstream gradient that lives on the device without a host sync.
+__global__ __launch_bounds__(kThreads) void k_scale_inplace(float *__restrict__ data, const float *__restrict__ scale,
+                                                            size_t n)
+{
+    const float s = scale[0];
+    if (s == 1.0f) return;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) data[i] *= s;
+}
+
 // ------------------------------------------------------------------------------------------
 // arithmetic self-check: div_rn / sqrt_rn against the compiler's IEEE `/` and sqrtf
 // ------------------------------------------------------------------------------------------
@@ -752,6 +763,16 @@ int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *target, const
     if (int e = launch_status("rendering_loss launch")) return e;
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), block, 0, st, partials, (int)(grid.x * grid.y), 1.0 / count, loss_out);
     return launch_status("loss_finalize launch");
+}
+
+int svbrdf_scale_inplace(float *data, const float *scale_dev, size_t n, void *stream)
+{
+    if (!data || !scale_dev) return fail(SVBRDF_ERR_NULL, "scale_inplace: null pointer");
+    if (n == 0) return 0;
+    const size_t blocks = (n + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(k_scale_inplace, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), data, scale_dev, n);
+    return launch_status("scale_inplace launch");
 }
 
 int svbrdf_debug_check_arith(unsigned long long n, unsigned seed, float lo, float hi,

@@ -46,11 +46,18 @@ class _FusedRenderingLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_loss):
+        if ctx.grads is None:
+            raise RuntimeError("the fused rendering loss was already back-propagated; its gradient buffer is "
+                               "scaled in place, so call forward again instead of retain_graph")
         grad_in, grad_tg = ctx.grads
         ctx.grads = None
-        gi = grad_in * grad_loss if grad_in is not None else None
-        gt = grad_tg * grad_loss if grad_tg is not None else None
-        return gi, gt, None, None
+        # chain rule through the scalar loss: scaled on the device, skipped when the upstream
+        # gradient is exactly 1 (loss.backward(), MixedLoss) -- no host sync either way
+        scale = grad_loss.detach().to(torch.float32).reshape(1)
+        for g in (grad_in, grad_tg):
+            if g is not None:
+                _native.scale_inplace_(g, scale)
+        return grad_in, grad_tg, None, None
 
 
 class RenderingLoss(nn.Module):
@@ -64,9 +71,10 @@ class RenderingLoss(nn.Module):
 
     def sample_scene_table(self, batch_size):
         """[B,S,9] on the host, reference RNG draw order (one item after the other)."""
-        return torch.stack([environment.scene_table(self.random_configuration_count,
-                                                    self.specular_configuration_count)
-                            for _ in range(batch_size)], dim=0)
+        key = (int(batch_size), int(self.random_configuration_count), int(self.specular_configuration_count))
+        if getattr(self, "_sampler_key", None) != key:
+            self._sampler, self._sampler_key = environment.BatchSceneSampler(*key), key
+        return self._sampler.sample()
 
     def forward(self, input, target):
         if input.dim() != 4 or input.shape != target.shape:

@@ -1,0 +1,66 @@
+"""CPU, world_size 2 over gloo: the multi-GPU story of the path.  The loss shards by batch with
+no data-path collective; the only collective is the scalar all-reduce used for reporting.
+The per-rank loss values come from the C oracle here (no GPU in this container) -- the
+sharding logic under test (shard bounds, per-rank scene RNG, mean of shard means) is the
+product's svbrdf_estimation_amd.distributed + RenderingLoss.sample_scene_table."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import synth
+    from oracle import c_oracle
+    from svbrdf_estimation_amd import distributed as D
+    from svbrdf_estimation_amd import losses, renderers
+
+    c_oracle.set_threads(2)
+    G, H = 4, 16
+    inp, tgt = synth.make_maps(301, G, H), synth.make_maps(302, G, H)
+    lo, hi = D.shard_bounds(G, rank, world)
+    fn = losses.RenderingLoss(renderers.LocalRenderer())
+    torch.manual_seed(D.rank_seed(313, rank))                 # per-rank scene RNG
+    table = fn.sample_scene_table(hi - lo).numpy()
+    local, grad = c_oracle.rendering_loss(inp[lo:hi], tgt[lo:hi], table)
+    glob = D.global_mean(torch.tensor(local, dtype=torch.float64))
+    # gather every rank's table/loss on rank 0 to check against the unsharded computation
+    tables = [None] * world
+    dist.all_gather_object(tables, (table, local, grad))
+    if rank == 0:
+        full_table = np.concatenate([t[0] for t in tables], axis=0)
+        full_loss, full_grad = c_oracle.rendering_loss(inp, tgt, full_table)
+        shard_grads = np.concatenate([t[2] for t in tables], axis=0) / world   # what DDP's averaging yields
+        np.save(out_path, np.array([glob.item(), full_loss, np.abs(shard_grads - full_grad).max(),
+                                    np.abs(full_grad).max(),
+                                    float(np.array_equal(tables[0][0], tables[1][0]))]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_unsharded(tmp_path):
+    port, out = _free_port(), str(tmp_path / "res.npy")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    glob, full, gerr, gmax, same_tables = np.load(out)
+    assert abs(glob - full) <= 1e-12 * abs(full)          # mean of equal shard means == global mean
+    assert gerr <= 1e-7 * gmax                            # averaged shard gradients == global-batch gradient
+    assert same_tables == 0.0                             # ranks drew different scenes

@@ -1,0 +1,197 @@
+"""CPU: host-side logic of the drop-in modules (scene sampler, SVBRDF packing helpers, error
+behaviour) and the C ABI's load/export contract.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ C ABI
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "svbrdf_hip.h")).read()
+    return re.findall(r"SVBRDF_API\s+[\w\s\*]+?\b(svbrdf_\w+)\s*\(", text)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from svbrdf_estimation_amd import _native
+    lib = _native._load()                     # dlopen + ABI version check, no GPU needed
+    names = _declared_symbols()
+    assert len(names) >= 9 and "svbrdf_rendering_loss_fwd_bwd" in names
+    for n in names:
+        assert hasattr(lib, n), "libsvbrdf_hip.so does not export %s" % n
+    assert lib.svbrdf_abi_version() == _native.ABI_VERSION
+
+
+def test_make_xrow_matches_reference_linspace_bits(golden):
+    from svbrdf_estimation_amd import _native
+    g = golden("g6_linspace.npz")
+    for k in g.files:
+        W = int(k[2:])
+        assert np.array_equal(_native.make_xrow_host(W).numpy().view(np.uint32), g[k].view(np.uint32)), W
+        assert torch.equal(_native.make_xrow_host(W), torch.linspace(-1, 1, W))
+
+
+def test_argument_errors_without_gpu():
+    from svbrdf_estimation_amd import _native
+    lib = _native._load()
+    assert lib.svbrdf_render_fwd(None, None, None, None, 1, 1, 4, 4, None) == -1
+    assert b"null" in lib.svbrdf_last_error()
+    assert lib.svbrdf_make_xrow(None, 4) == -1
+    assert lib.svbrdf_rendering_loss_workspace_bytes(8, 9, 256, 256) == 8 * 256 * 4
+    assert lib.svbrdf_rendering_loss_workspace_bytes(0, 9, 256, 256) == 0
+
+
+def test_no_cpu_fallback():
+    """the product path must fail loudly on CPU tensors instead of computing somewhere else"""
+    from svbrdf_estimation_amd import NativeLibraryError, environment, losses, renderers
+    sc = environment.Scene(environment.Camera([0, 0, 2.0]), environment.Light([0, 0, 2.0], [1.0, 1.0, 1.0]))
+    with pytest.raises(NativeLibraryError):
+        renderers.LocalRenderer().render(sc, torch.zeros(12, 8, 8))
+    with pytest.raises(NativeLibraryError):
+        losses.RenderingLoss(renderers.LocalRenderer())(torch.zeros(1, 12, 8, 8), torch.zeros(1, 12, 8, 8))
+    with pytest.raises(ValueError):
+        losses.RenderingLoss(renderers.LocalRenderer())(torch.zeros(12, 8, 8), torch.zeros(12, 8, 8))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "svbrdf_estimation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower() or f == "__init__.py" and "oracle" not in text, (
+                    "%s mentions the oracle" % os.path.join(dirpath, f))
+
+
+# ------------------------------------------------------------------ scene sampler (environment.py)
+
+def test_scene_sampler_bit_exact_vs_reference(golden):
+    from svbrdf_estimation_amd import environment as env, utils
+    g = golden("g5_scene_sampler.npz")
+    for seed in (0, 7, 313):
+        torch.manual_seed(seed)
+        assert np.array_equal(env.scene_table(3, 6).numpy(), g["seed_%d" % seed]), seed
+    torch.manual_seed(5)
+    assert np.array_equal(env.scene_table(11, 21).numpy(), g["seed_5_11_21"])
+    torch.manual_seed(3)
+    assert np.array_equal(utils.generate_normalized_random_direction(8, 0.001, 0.05).numpy(), g["seed_3_dirs_8"])
+    # SURVEY.md section 4 known answers (seed 7)
+    torch.manual_seed(7)
+    scenes = env.generate_random_scenes(3) + env.generate_specular_scenes(6)
+    np.testing.assert_allclose(scenes[0].camera.pos.numpy(), [-0.38334444, -0.57874203, 0.71979487], rtol=1e-6)
+    np.testing.assert_allclose(scenes[3].light.pos.numpy(), [-4.70324516, 0.05648994, 8.91850853], rtol=1e-6)
+    assert scenes[0].light.color == [20.0, 20.0, 20.0] and scenes[3].light.color == [50.0, 50.0, 50.0]
+    assert torch.equal(env.scene_to_row(scenes[3]), torch.from_numpy(g["seed_7"][3]))
+
+
+@pytest.mark.parametrize("B,R,M", [(8, 3, 6), (2, 11, 21), (1, 3, 6), (5, 0, 4), (3, 2, 0), (2, 17, 40)])
+def test_batch_sampler_equals_per_item_draws_and_rng_state(B, R, M):
+    from svbrdf_estimation_amd import environment as env
+    samp = env.BatchSceneSampler(B, R, M)
+    for seed in range(25):
+        torch.manual_seed(seed)
+        a = torch.stack([env.scene_table(R, M) for _ in range(B)])
+        sa = torch.get_rng_state()
+        torch.manual_seed(seed)
+        b = samp.sample()
+        assert torch.equal(a, b) and torch.equal(sa, torch.get_rng_state()), (B, R, M, seed)
+
+
+def test_rendering_loss_sampling_order_matches_reference(golden):
+    from svbrdf_estimation_amd import losses, renderers
+    g = golden("g5_scene_sampler.npz")
+    fn = losses.RenderingLoss(renderers.LocalRenderer())
+    assert (fn.random_configuration_count, fn.specular_configuration_count) == (3, 6)
+    torch.manual_seed(99)
+    assert np.array_equal(fn.sample_scene_table(2).numpy(), g["seed_99_two_items"])
+    g3 = golden("g3_loss_7_s5.npz")
+    fn.random_configuration_count, fn.specular_configuration_count = int(g3["n_random"]), int(g3["n_specular"])
+    torch.manual_seed(int(g3["rng_seed"]))
+    assert np.array_equal(fn.sample_scene_table(3).numpy(), g3["scenes"])
+
+
+# ------------------------------------------------------------------ utils.py
+
+def test_utils_against_reference(golden):
+    from svbrdf_estimation_amd import utils
+    g = golden("g8_utils.npz")
+    x = torch.from_numpy(g["enc9"]).requires_grad_(True)
+    dec = utils.decode_svbrdf(x)
+    assert np.array_equal(dec.detach().numpy(), g["decoded12"])
+    dec.backward(torch.from_numpy(g["cot"]))
+    np.testing.assert_allclose(x.grad.numpy(), g["grad9"], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(utils.decode_svbrdf(torch.from_numpy(g["enc9"][0])).numpy(), g["decoded12_single"])
+    img = torch.from_numpy(g["img"])
+    assert np.array_equal(utils.gamma_encode(img).numpy(), g["gamma_enc"])
+    assert np.array_equal(utils.gamma_decode(img).numpy(), g["gamma_dec"])
+    assert np.array_equal(utils.encode_as_unit_interval(torch.from_numpy(g["enc9"])).numpy(), g["unit"])
+    assert np.array_equal(utils.decode_from_unit_interval(img).numpy(), g["from_unit"])
+    n, d, r, s = utils.unpack_svbrdf(torch.from_numpy(g["maps404"]))
+    for a, k in ((n, "n"), (d, "d"), (r, "r"), (s, "s")):
+        assert np.array_equal(a.numpy(), g[k])
+    assert np.array_equal(utils.pack_svbrdf(n, d, r, s).numpy(), g["repacked"])
+    with pytest.raises(ValueError):
+        utils.unpack_svbrdf(torch.zeros(9, 4, 4))
+
+
+def test_reference_unit_test_constants():
+    """the reference's own unit tests (utils.py:149-247): gamma magic pixel, channel order"""
+    from svbrdf_estimation_amd import utils
+    enc = torch.tensor([[[1.3703509847201]], [[1.3703509847201]]])
+    torch.testing.assert_close(utils.gamma_decode(enc), torch.full_like(enc, 2.0))
+    torch.testing.assert_close(utils.gamma_encode(torch.full_like(enc, 2.0)), enc)
+    torch.testing.assert_close(utils.gamma_decode(enc.unsqueeze(0).repeat(5, 1, 1, 1)), torch.full((5, 2, 1, 1), 2.0))
+    nv = 1.0 / 3.0 ** 0.5
+    n = torch.full((3, 1, 1), nv)
+    d = torch.tensor([0.1, 0.2, 0.3]).view(3, 1, 1)
+    r = torch.full((3, 1, 1), 0.3)
+    s = torch.tensor([0.4, 0.5, 0.6]).view(3, 1, 1)
+    sv = utils.pack_svbrdf(n, d, r, s)
+    assert tuple(sv.shape) == (12, 1, 1)
+    assert torch.equal(sv[0:3], n) and torch.equal(sv[3:6], d) and torch.equal(sv[6:9], r) and torch.equal(sv[9:12], s)
+    batch = sv.repeat(5, 1, 1, 1)
+    bn, bd, br, bs = utils.unpack_svbrdf(batch)
+    assert tuple(bd.shape) == (5, 3, 1, 1) and torch.equal(bs[2], s) and torch.equal(bn[4], n)
+
+
+def test_l1_and_plugin_losses_on_cpu(golden):
+    """SVBRDFL1Loss is stock torch and the plugin path works with any foreign renderer on any device"""
+    from svbrdf_estimation_amd import losses
+    g = golden("g3_loss_48.npz")
+    x = torch.from_numpy(g["input"]).requires_grad_(True)
+    l1 = losses.SVBRDFL1Loss()(x, torch.from_numpy(g["target"]))
+    l1.backward()
+    assert abs(l1.item() - float(g["l1_loss"])) <= 1e-6 * float(g["l1_loss"])
+    np.testing.assert_allclose(x.grad.numpy(), g["l1_grad"], rtol=1e-5, atol=1e-9)
+
+    class Flat:
+        calls = 0
+
+        def render(self, scene, svbrdf):
+            Flat.calls += 1
+            return svbrdf[3:6].unsqueeze(0) * float(scene.light.color[0])
+
+    fn = losses.RenderingLoss(Flat())
+    fn.random_configuration_count, fn.specular_configuration_count = 1, 2
+    torch.manual_seed(0)
+    loss = fn(torch.rand(2, 12, 4, 4), torch.rand(2, 12, 4, 4))
+    assert loss.dim() == 0 and Flat.calls == 2 * 2 * 3
+    mixed = losses.MixedLoss(Flat(), l1_weight=0.25)
+    assert mixed.l1_weight == 0.25 and isinstance(mixed.rendering_loss, losses.RenderingLoss)
+
+
+def test_shard_helpers():
+    from svbrdf_estimation_amd import distributed as D
+    assert [D.shard_bounds(64, r, 8) for r in (0, 7)] == [(0, 8), (56, 64)]
+    with pytest.raises(ValueError):
+        D.shard_bounds(10, 0, 4)
+    t = torch.arange(12).view(6, 2)
+    assert torch.equal(D.shard(t, 1, 3), t[2:4])
+    assert D.rank_seed(313, 5) == 318
+    assert torch.equal(D.global_mean(torch.tensor(2.0)), torch.tensor(2.0))   # no process group: identity
