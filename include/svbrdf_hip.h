@@ -74,7 +74,11 @@ SVBRDF_API int svbrdf_render_bwd(const float *maps, const float *scenes, const f
                       const float *grad_out, float *grad_maps,
                       int B, int S, int H, int W, void *stream);
 
-/* bytes of device scratch svbrdf_rendering_loss_fwd_bwd needs for these dims */
+/* Bytes of device scratch svbrdf_rendering_loss_fwd_bwd needs for these dims (65 64-bit
+ * words: sharded fixed-point loss accumulators with arrival counts, and a ticket).  The scratch must be
+ * 8-byte aligned and ZERO-INITIALISED ONCE by the caller (hipMemset) before its first use;
+ * every completed call leaves it zeroed again, so it can be reused call after call on
+ * the same stream.  Do not share one scratch buffer between concurrently running calls. */
 SVBRDF_API size_t svbrdf_rendering_loss_workspace_bytes(int B, int S, int H, int W);
 
 /* K3 -- replaces RenderingLoss.forward AND its backward (losses.py:29-52):

@@ -115,8 +115,9 @@ def _workspace(device, nbytes):
     # one scratch buffer per (device, stream): calls on different streams never share it
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     t = _workspace_cache.get(key)
-    if t is None or t.numel() * 4 < nbytes:
-        t = torch.empty((max(nbytes, 4096) + 3) // 4, dtype=torch.float32, device=device)
+    if t is None or t.numel() * 8 < nbytes:
+        # zero-initialised once; every completed kernel leaves it zeroed (see svbrdf_hip.h)
+        t = torch.zeros((max(nbytes, 64) + 7) // 8, dtype=torch.int64, device=device)
         _workspace_cache[key] = t
     return t
 
@@ -190,7 +191,7 @@ def rendering_loss(input, target, scenes, eps=0.1, want_grad=True):
         rc = lib.svbrdf_rendering_loss_fwd_bwd(
             input.data_ptr(), target.data_ptr(), scenes.data_ptr(), xr.data_ptr(),
             ctypes.c_float(eps), loss.data_ptr(), grad.data_ptr() if want_grad else None,
-            ws.data_ptr(), ws.numel() * 4, B, S, H, W, _stream(input.device))
+            ws.data_ptr(), ws.numel() * 8, B, S, H, W, _stream(input.device))
         if hook is not None:
             hook("end")
     _check(rc, "svbrdf_rendering_loss_fwd_bwd")

@@ -167,107 +167,139 @@ __device__ __forceinline__ MapK prepare(const Maps &m)
     return k;
 }
 
-struct Ctx {            // forward values the adjoint needs
+// The network emits ONE roughness channel repeated three times (utils.py:78-80
+// decode_svbrdf) and the Deschaintre data stores grey roughness, so the three colour
+// channels usually share alpha -- and with it the whole GGX D and Smith G evaluation.
+__device__ __forceinline__ bool tied_roughness(const Maps &m) { return m.r[0] == m.r[1] && m.r[1] == m.r[2]; }
+
+struct Dots {           // clamped dot products of one (pixel, scene, map set) and what hangs off them
     float nh_raw, vn_raw, ln_raw;
-    float NH, NH2, uV, uL, iVN, iLN, iq, LNp;
-    float F[3], Gp[3], D[3], spec[3], f[3];
-    float rV[3], rL[3], iwV[3], iwL[3];
-    float ipd2[3], pd[3];
-    bool den_on[3];
+    float NH, NH2, oN;  // NH^2 and 1 - NH^2, rounded exactly like the reference's
+    float iVN, iLN, iq; // 1/VN, 1/LN, 1/(VN LN)
+    float uV, uL;       // (1 - XN^2)/XN^2
+    float LNp;          // clamp(n.wi, 0)                       renderers.py:96
 };
 
-// map-dependent part of render(): renderers.py:43-65, 95-100.
-// The three clamped dot products and 1-NH^2 follow the reference's rounding exactly; the
-// rest uses v_rcp/v_rsq (1 ULP each) -- the result differs from the op-by-op evaluation
-// by a few 1e-7 relative, 50x inside the parity budget.
-template <bool KEEP>
-__device__ __forceinline__ void shade(const Geom &g, const MapK &m, float rad[3], Ctx &c)
+// renderers.py:48-52, 96.  The three dot products and 1-NH^2 follow the reference's
+// rounding exactly; everything derived from them is well conditioned (v_rcp, 1 ULP).
+__device__ __forceinline__ Dots dots(const Geom &g, const MapK &m)
 {
-    const float nh_raw = dot3(m.n[0], m.n[1], m.n[2], g.hx, g.hy, g.hz);
-    const float vn_raw = dot3(g.wox, g.woy, g.woz, m.n[0], m.n[1], m.n[2]);
-    const float ln_raw = dot3(g.wix, g.wiy, g.wiz, m.n[0], m.n[1], m.n[2]);
-    const float NH = fmaxf(nh_raw, kMinDot), VN = fmaxf(vn_raw, kMinDot), LN = fmaxf(ln_raw, kMinDot);
-    const float LNp = fmaxf(ln_raw, 0.0f);
-    const float NH2 = NH * NH, VN2 = VN * VN, LN2 = LN * LN;
-    const float iN = (1.0f - NH2) * rcp_(NH2);            // (1 - NH^2) / NH^2
-    const float iVN = rcp_(VN), iLN = rcp_(LN);
-    const float uV = (1.0f - VN2) * (iVN * iVN);          // (1 - VN^2) / VN^2
-    const float uL = (1.0f - LN2) * (iLN * iLN);
-    const float iq = iVN * iLN;                           // 4/(4 VN LN): the 4 cancels against G1V*G1L
-    if (KEEP) {
-        c.nh_raw = nh_raw; c.vn_raw = vn_raw; c.ln_raw = ln_raw;
-        c.NH = NH; c.NH2 = NH2; c.uV = uV; c.uL = uL; c.iVN = iVN; c.iLN = iLN; c.iq = iq; c.LNp = LNp;
+    Dots d;
+    d.nh_raw = dot3(m.n[0], m.n[1], m.n[2], g.hx, g.hy, g.hz);
+    d.vn_raw = dot3(g.wox, g.woy, g.woz, m.n[0], m.n[1], m.n[2]);
+    d.ln_raw = dot3(g.wix, g.wiy, g.wiz, m.n[0], m.n[1], m.n[2]);
+    d.NH = fmaxf(d.nh_raw, kMinDot);
+    const float VN = fmaxf(d.vn_raw, kMinDot), LN = fmaxf(d.ln_raw, kMinDot);
+    d.LNp = fmaxf(d.ln_raw, 0.0f);
+    d.NH2 = d.NH * d.NH;
+    d.oN = 1.0f - d.NH2;
+    d.iq = rcp_(VN * LN);               // the 4 of 4*VN*LN cancels against the 2*2 of G1V*G1L
+    d.iVN = d.iq * LN;
+    d.iLN = d.iq * VN;
+    d.uV = (1.0f - VN * VN) * (d.iVN * d.iVN);
+    d.uL = (1.0f - LN * LN) * (d.iLN * d.iLN);
+    return d;
+}
+
+// Everything of the specular term that depends on the material only through alpha^2 = A:
+//   GD = G*D/4 = A / (pi den^2 (1+wV)(1+wL)),   wX = sqrt(1 + A uX)      renderers.py:22-41
+//   den = NH^2 (A + (1-NH^2)/NH^2) = NH^2 A + (1-NH^2)   (one rounding instead of three)
+// and, for the adjoint, its partial derivatives per unit of d(loss)/d(GD):
+//   KA = dGD/dA (den clamp mask applied), KV/KL = dGD/duV, dGD/duL, KN = dGD/d(NH^2).
+struct Lobe {
+    float GD, KA, KV, KL, KN;
+};
+
+template <bool BWD>
+__device__ __forceinline__ Lobe lobe(float A, const Dots &d)
+{
+    Lobe l;
+    const float xV = fma_(A, d.uV, 1.0f), xL = fma_(A, d.uL, 1.0f);
+    // sqrt as x*rsq(x) in the forward-only and the forward+backward instantiation alike, so
+    // that input and target shading are the SAME arithmetic (identical maps -> loss exactly 0)
+    const float iwV = rsq_(xV), iwL = rsq_(xL);
+    const float wV = xV * iwV, wL = xL * iwL;
+    const float aV = 1.0f + wV, aL = 1.0f + wL;
+    const float M = aV * aL;                            // 4/G
+    const float den_raw = fma_(d.NH2, A, d.oN);
+    const float den = fmaxf(den_raw, kMinDen);          // renderers.py:26 clamp
+    const float pd = kPi * den;
+    const float Q = pd * den;                           // A/D
+    const float R = rcp_(M * Q);
+    l.GD = A * R;
+    if (BWD) {
+        const float RQ = R * Q;                         // 1/M
+        const float hGD = -0.5f * l.GD;
+        const float KxV = hGD * ((RQ * aL) * iwV);      // dGD/dxV = -GD/(2 wV (1+wV))
+        const float KxL = hGD * ((RQ * aV) * iwL);
+        // dGD/dden = -2 GD/den, 1/den = (R M) pd; zero where the clamp is active
+        const float Kden = (den_raw >= kMinDen) ? (-2.0f * l.GD) * ((R * M) * pd) : 0.0f;
+        l.KA = fma_(KxV, d.uV, fma_(KxL, d.uL, fma_(Kden, d.NH2, R)));
+        l.KV = KxV * A;
+        l.KL = KxL * A;
+        l.KN = Kden * (A - 1.0f);                       // d den_raw/d(NH^2) = A - 1
     }
+    return l;
+}
+
+// radiance of one pixel under one scene: renderers.py:43-65, 95-100.  NL = 3: one lobe per
+// colour channel (independent roughness channels); NL = 1: tied roughness, one lobe.
+template <int NL, bool BWD>
+__device__ __forceinline__ void shade(const Geom &g, const MapK &m, const Dots &d, Lobe lb[NL],
+                                      float F[3], float f[3], float rad[3])
+{
+#pragma unroll
+    for (int l = 0; l < NL; ++l) lb[l] = lobe<BWD>(m.A[l], d);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float A = m.A[k];
-        const float F = fma_(m.oms[k], g.p, m.s[k]);                  // Schlick
-        const float xV = fma_(A, uV, 1.0f), xL = fma_(A, uL, 1.0f);   // 1 + A (1-XN^2)/XN^2
-        const float iwV = rsq_(xV), iwL = rsq_(xL);
-        const float rV = rcp_(fma_(xV, iwV, 1.0f));                   // 1/(1 + sqrt(xV)) = G1V/2
-        const float rL = rcp_(fma_(xL, iwL, 1.0f));
-        const float Gp = rV * rL;                                     // G/4
-        const float den_raw = NH2 * (A + iN);
-        const float den = fmaxf(den_raw, kMinDen);
-        const float pd = kPi * den;
-        const float ipd2 = rcp_(pd * den);
-        const float D = A * ipd2;                                     // GGX
-        const float spec = ((F * Gp) * D) * iq;
-        const float f = fma_(1.0f - F, m.dpi[k], spec);
-        rad[k] = f * (g.E[k] * LNp);
-        if (KEEP) {
-            c.F[k] = F; c.Gp[k] = Gp; c.D[k] = D; c.spec[k] = spec; c.f[k] = f;
-            c.rV[k] = rV; c.rL[k] = rL; c.iwV[k] = iwV; c.iwL[k] = iwL;
-            c.ipd2[k] = ipd2; c.pd[k] = pd; c.den_on[k] = den_raw >= kMinDen;
-        }
+        F[k] = fma_(m.oms[k], g.p, m.s[k]);                               // Schlick, renderers.py:29-32
+        const float spec = (F[k] * lb[NL == 3 ? k : 0].GD) * d.iq;
+        f[k] = fma_(1.0f - F[k], m.dpi[k], spec);                         // renderers.py:18-20, 62-65
+        rad[k] = f[k] * (g.E[k] * d.LNp);
     }
 }
 
 // adjoint of shade() with PyTorch's sub-gradient conventions: clamp(min=m) passes the
 // gradient iff x >= m (inclusive); xi() has zero gradient (renderers.py:15-16).
-__device__ __forceinline__ void shade_bwd(const Geom &g, const MapK &m, const Ctx &c,
-                                          const float g_rad[3], Grad &acc)
+template <int NL>
+__device__ __forceinline__ void shade_bwd(const Geom &g, const MapK &m, const Dots &d, const Lobe lb[NL],
+                                          const float F[3], const float f[3], const float g_rad[3], Grad &acc)
 {
-    float g_LNp = 0.0f, sNH = 0.0f, sV = 0.0f, sL = 0.0f, sSp = 0.0f;
+    float g_LNp = 0.0f, sSp = 0.0f, W[NL];
     constexpr float inv_pi = 1.0f / kPi;
 #pragma unroll
+    for (int l = 0; l < NL; ++l) W[l] = 0.0f;
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
+        const Lobe &l = lb[NL == 3 ? k : 0];
         const float gE = g_rad[k] * g.E[k];
-        const float g_f = gE * c.LNp;
-        g_LNp = fma_(gE, c.f[k], g_LNp);
-        const float gfq = g_f * c.iq;
-        const float GD = c.Gp[k] * c.D[k];
-        const float g_F = fma_(gfq, GD, -(g_f * m.dpi[k]));
+        const float g_f = gE * d.LNp;
+        g_LNp = fma_(gE, f[k], g_LNp);
+        const float gfq = g_f * d.iq;
+        const float g_F = fma_(gfq, l.GD, -(g_f * m.dpi[k]));             // f = (1-F) d/pi + F GD iq
         acc.s[k] = fma_(g_F, 1.0f - g.p, acc.s[k]);
-        acc.d[k] = fma_(g_f * (1.0f - c.F[k]), inv_pi, acc.d[k]);
-        const float gfqF = gfq * c.F[k];
-        const float g_Gp = gfqF * c.D[k];          // d/dGp
-        const float g_D = gfqF * c.Gp[k];
-        sSp = fma_(g_f, c.spec[k], sSp);
-        // Gp = rV*rL, rX = 1/(1+wX), wX = sqrt(xX), xX = 1 + A*uX:  dGp/dxV = -Gp*rV/(2 wV)
-        const float gG = g_Gp * c.Gp[k];
-        const float g_xV = (-0.5f * gG) * (c.rV[k] * c.iwV[k]);
-        const float g_xL = (-0.5f * gG) * (c.rL[k] * c.iwL[k]);
-        float g_A = fma_(g_xV, c.uV, g_xL * c.uL);
-        sV = fma_(g_xV, m.A[k], sV);               // d xV / d uV = A
-        sL = fma_(g_xL, m.A[k], sL);
-        // D = A/(pi den^2)
-        g_A = fma_(g_D, c.ipd2[k], g_A);
-        const float iden = c.ipd2[k] * c.pd[k];    // 1/den
-        const float g_den = c.den_on[k] ? (-2.0f * g_D) * (c.D[k] * iden) : 0.0f;
-        // den_raw = m*(A + (1-m)/m), m = NH^2:  d/dA = m, d/dm = A - 1
-        g_A = fma_(g_den, c.NH2, g_A);
-        sNH = fma_(g_den, m.A[k] - 1.0f, sNH);
-        acc.r[k] = fma_(g_A, m.r4m[k], acc.r[k]);
+        acc.d[k] = fma_(g_f * (1.0f - F[k]), inv_pi, acc.d[k]);
+        const float gGD = gfq * F[k];                                     // d loss/d GD
+        sSp = fma_(gGD, l.GD, sSp);                                       // sum of g_f * spec / iq ... see below
+        acc.r[k] = fma_(gGD * l.KA, m.r4m[k], acc.r[k]);
+        W[NL == 3 ? k : 0] += gGD;
     }
-    // uX = 1/XN^2 - 1: d uX/d XN = -2/XN^3 ; spec ~ 1/(VN LN)
-    float g_NH = (sNH * 2.0f) * c.NH;
-    float g_VN = -c.iVN * fma_(2.0f * sV, c.iVN * c.iVN, sSp);
-    float g_LN = -c.iLN * fma_(2.0f * sL, c.iLN * c.iLN, sSp);
-    if (!(c.nh_raw >= kMinDot)) g_NH = 0.0f;
-    if (!(c.vn_raw >= kMinDot)) g_VN = 0.0f;
-    if (!(c.ln_raw >= kMinDot)) g_LN = 0.0f;
-    if (!(c.ln_raw >= 0.0f)) g_LNp = 0.0f;
+    float sV = 0.0f, sL = 0.0f, sN = 0.0f;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        sV = fma_(W[l], lb[l].KV, sV);
+        sL = fma_(W[l], lb[l].KL, sL);
+        sN = fma_(W[l], lb[l].KN, sN);
+    }
+    // uX = 1/XN^2 - 1: d uX/d XN = -2/XN^3;  spec = F GD/(VN LN): d spec/d XN = -spec/XN
+    // (sSp = sum_k g_f F GD iq = sum_k g_f spec_k)
+    float g_NH = (sN * 2.0f) * d.NH;
+    float g_VN = -d.iVN * fma_(2.0f * sV, d.iVN * d.iVN, sSp);
+    float g_LN = -d.iLN * fma_(2.0f * sL, d.iLN * d.iLN, sSp);
+    if (!(d.nh_raw >= kMinDot)) g_NH = 0.0f;
+    if (!(d.vn_raw >= kMinDot)) g_VN = 0.0f;
+    if (!(d.ln_raw >= kMinDot)) g_LN = 0.0f;
+    if (!(d.ln_raw >= 0.0f)) g_LNp = 0.0f;
     const float gl = g_LN + g_LNp;
     acc.n[0] = fma_(g_NH, g.hx, fma_(g_VN, g.wox, fma_(gl, g.wix, acc.n[0])));
     acc.n[1] = fma_(g_NH, g.hy, fma_(g_VN, g.woy, fma_(gl, g.wiy, acc.n[1])));
@@ -375,27 +407,11 @@ __device__ __forceinline__ void load_scene(const float *__restrict__ p, float sc
 // ------------------------------------------------------------------------------------------
 // K1: render forward.  grid = (ceil(H*W / (256*VEC)), B); S renders per map in one pass.
 // ------------------------------------------------------------------------------------------
-template <int VEC>
-__global__ __launch_bounds__(kThreads) void k_render_fwd(const float *__restrict__ maps,
-                                                         const float *__restrict__ scenes,
-                                                         const float *__restrict__ xrow,
-                                                         float *__restrict__ out, int S, int H, int W)
+template <int VEC, int NL>
+__device__ __forceinline__ void render_fwd_loop(const MapK mk[VEC], const float x[VEC], float y,
+                                                const float *__restrict__ scp, float *__restrict__ o,
+                                                size_t plane, int S)
 {
-    const size_t plane = (size_t)H * W;
-    const size_t pix = ((size_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
-    const int b = blockIdx.y;
-    if (pix >= plane) return;
-    MapK mk[VEC];
-    {
-        Maps m[VEC];
-        load_maps<VEC>(maps + (size_t)b * 12 * plane, plane, pix, m);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) mk[v] = prepare<false>(m[v]);
-    }
-    float x[VEC], y;
-    pixel_coords<VEC>(xrow, pix, W, x, y);
-    const float *__restrict__ scp = scenes + (size_t)b * S * 9;
-    float *__restrict__ o = out + (size_t)b * S * 3 * plane + pix;
     for (int s = 0; s < S; ++s, scp += 9, o += 3 * plane) {
         float sc[9];
         load_scene(scp, sc);
@@ -403,8 +419,10 @@ __global__ __launch_bounds__(kThreads) void k_render_fwd(const float *__restrict
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const Geom g = geometry(sc, x[v], y);
-            Ctx unused;
-            shade<false>(g, mk[v], rad[v], unused);
+            const Dots d = dots(g, mk[v]);
+            Lobe lb[NL];
+            float F[3], f[3];
+            shade<NL, false>(g, mk[v], d, lb, F, f, rad[v]);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -416,10 +434,63 @@ __global__ __launch_bounds__(kThreads) void k_render_fwd(const float *__restrict
     }
 }
 
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void k_render_fwd(const float *__restrict__ maps,
+                                                         const float *__restrict__ scenes,
+                                                         const float *__restrict__ xrow,
+                                                         float *__restrict__ out, int S, int H, int W)
+{
+    const size_t plane = (size_t)H * W;
+    const size_t pix = ((size_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
+    const int b = blockIdx.y;
+    if (pix >= plane) return;
+    MapK mk[VEC];
+    bool tied = true;
+    {
+        Maps m[VEC];
+        load_maps<VEC>(maps + (size_t)b * 12 * plane, plane, pix, m);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            mk[v] = prepare<false>(m[v]);
+            tied = tied && tied_roughness(m[v]);
+        }
+    }
+    float x[VEC], y;
+    pixel_coords<VEC>(xrow, pix, W, x, y);
+    const float *__restrict__ scp = scenes + (size_t)b * S * 9;
+    float *__restrict__ o = out + (size_t)b * S * 3 * plane + pix;
+    if (__all(tied)) render_fwd_loop<VEC, 1>(mk, x, y, scp, o, plane, S);      // wave-uniform branch
+    else render_fwd_loop<VEC, 3>(mk, x, y, scp, o, plane, S);
+}
+
 // ------------------------------------------------------------------------------------------
 // K2: render backward.  Same grid; the S scenes of one map are accumulated in-thread
 // (no atomics), the forward is recomputed in registers.
 // ------------------------------------------------------------------------------------------
+template <int VEC, int NL>
+__device__ __forceinline__ void render_bwd_loop(const MapK mk[VEC], const float x[VEC], float y,
+                                                const float *__restrict__ scp, const float *__restrict__ go,
+                                                size_t plane, int S, Grad acc[VEC])
+{
+    for (int s = 0; s < S; ++s, scp += 9, go += 3 * plane) {
+        float sc[9];
+        load_scene(scp, sc);
+        float gr[3][VEC];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) load_vec<VEC>(go + (size_t)k * plane, gr[k]);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const Geom g = geometry(sc, x[v], y);
+            const Dots d = dots(g, mk[v]);
+            Lobe lb[NL];
+            float F[3], f[3], rad[3];
+            shade<NL, true>(g, mk[v], d, lb, F, f, rad);
+            const float g_rad[3] = {gr[0][v], gr[1][v], gr[2][v]};
+            shade_bwd<NL>(g, mk[v], d, lb, F, f, g_rad, acc[v]);
+        }
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void k_render_bwd(const float *__restrict__ maps,
                                                          const float *__restrict__ scenes,
@@ -432,11 +503,15 @@ __global__ __launch_bounds__(kThreads) void k_render_bwd(const float *__restrict
     const int b = blockIdx.y;
     if (pix >= plane) return;
     MapK mk[VEC];
+    bool tied = true;
     {
         Maps m[VEC];
         load_maps<VEC>(maps + (size_t)b * 12 * plane, plane, pix, m);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) mk[v] = prepare<true>(m[v]);
+        for (int v = 0; v < VEC; ++v) {
+            mk[v] = prepare<true>(m[v]);
+            tied = tied && tied_roughness(m[v]);
+        }
     }
     float x[VEC], y;
     pixel_coords<VEC>(xrow, pix, W, x, y);
@@ -445,22 +520,8 @@ __global__ __launch_bounds__(kThreads) void k_render_bwd(const float *__restrict
     for (int v = 0; v < VEC; ++v) zero_grad(acc[v]);
     const float *__restrict__ scp = scenes + (size_t)b * S * 9;
     const float *__restrict__ go = grad_out + (size_t)b * S * 3 * plane + pix;
-    for (int s = 0; s < S; ++s, scp += 9, go += 3 * plane) {
-        float sc[9];
-        load_scene(scp, sc);
-        float gr[3][VEC];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) load_vec<VEC>(go + (size_t)k * plane, gr[k]);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            const Geom g = geometry(sc, x[v], y);
-            Ctx c;
-            float rad[3];
-            shade<true>(g, mk[v], rad, c);
-            const float g_rad[3] = {gr[0][v], gr[1][v], gr[2][v]};
-            shade_bwd(g, mk[v], c, g_rad, acc[v]);
-        }
-    }
+    if (__all(tied)) render_bwd_loop<VEC, 1>(mk, x, y, scp, go, plane, S, acc);
+    else render_bwd_loop<VEC, 3>(mk, x, y, scp, go, plane, S, acc);
     store_grads<VEC>(grad_maps + (size_t)b * 12 * plane, plane, pix, acc);
 }
 
@@ -469,8 +530,15 @@ __global__ __launch_bounds__(kThreads) void k_render_bwd(const float *__restrict
 //   per pixel: read 12 input + 12 target planes once, loop the S scenes in registers
 //   (geometry shared by input and target), accumulate |dlog| and the 12 map gradients,
 //   write 12 gradient planes once  -> 144 B/pixel of HBM traffic, independent of S.
-//   Loss: per-thread fp32 sum -> wave shuffle -> LDS -> one partial per workgroup;
-//   k_loss_finalize sums the partials in a fixed order in fp64 (deterministic).
+//   Loss: per-thread fp32 sum -> wave shuffle -> LDS -> one value per workgroup, added as a
+//   fixed-point integer to one of kLossSlots 64-bit accumulators (integer addition is
+//   associative, so the result is bitwise reproducible whatever the arrival order).  Each
+//   accumulator word also counts its arrivals in its top 16 bits, so ONE returning atomic
+//   per workgroup both adds and tells the workgroup whether it completed its slot; slot
+//   completers draw a global ticket (<= kLossSlots atomics in all) and the last of them sums
+//   the slots, writes the mean and re-zeroes the scratch.  (A single shared accumulator +
+//   ticket serialises 2 atomics per workgroup on one address and cost ~45 us at 2048
+//   workgroups -- measured; profiles/r01_k3_sweep.txt.)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -479,16 +547,87 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+constexpr int kLossSlots = 64;                    // sharded accumulators (power of two)
+constexpr int kLossCountShift = 48;               // word = arrivals << 48 | fixed-point sum
+constexpr unsigned long long kLossSumMask = (1ULL << kLossCountShift) - 1;
+
+// one (pixel, scene) of the fused loss: both shadings, log/L1, adjoint of the input shading
+template <int NL, bool WITH_GRAD>
+__device__ __forceinline__ void loss_pixel_scene(const float sc[9], float x, float y, const MapK &mi, const MapK &mt,
+                                                 float eps, float inv_count, float &lsum, Grad &acc)
+{
+    constexpr float kLn2 = 0.693147180559945309417f;
+    const Geom g = geometry(sc, x, y);
+    float rt[3];
+    {
+        const Dots dt = dots(g, mt);
+        Lobe lt[NL];
+        float Ft[3], ft[3];
+        shade<NL, false>(g, mt, dt, lt, Ft, ft, rt);
+    }
+    const Dots di = dots(g, mi);
+    Lobe li[NL];
+    float Fi[3], fi[3], ri[3], g_rad[3];
+    shade<NL, WITH_GRAD>(g, mi, di, li, Fi, fi, ri);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // losses.py:46-50: |log(ri + eps) - log(rt + eps)|, v_log_f32 = log2
+        const float ai = ri[k] + eps, at = rt[k] + eps;
+        const float delta = kLn2 * (__builtin_amdgcn_logf(ai) - __builtin_amdgcn_logf(at));
+        lsum += fabsf(delta);
+        // d|delta|/d ri = sign(delta)/(N*ai), sign(0) = 0 as in torch
+        const float sg = __builtin_amdgcn_fmed3f(delta * 1.0e30f, -1.0f, 1.0f);
+        g_rad[k] = sg * (inv_count * rcp_(ai));
+    }
+    if (WITH_GRAD) shade_bwd<NL>(g, mi, di, li, Fi, fi, g_rad, acc);
+}
+
+// Scene loop of K3, unrolled by two with the scene scalars double-buffered in SGPRs: the
+// scalar loads of render s+1 are issued before the arithmetic of render s (sched_barrier
+// keeps them there) so their latency never sits on the critical path.
+template <int VEC, int NL, bool WITH_GRAD>
+__device__ __forceinline__ float loss_scene_loop(const MapK mi[VEC], const MapK mt[VEC], const float x[VEC], float y,
+                                                 const float *__restrict__ scp, int S, float eps, float inv_count,
+                                                 Grad acc[VEC])
+{
+    float lsum = 0.0f;
+    float scA[9], scB[9];
+    load_scene(scp, scA);
+    for (int s = 0;; s += 2, scp += 18) {
+        // Scalar loads return out of order, so a wait on them is always "all outstanding":
+        // consume the current buffer FIRST (the compiler puts its s_waitcnt here), only then
+        // issue the loads for the other buffer, and pin that order.
+        asm volatile("" ::"s"(scA[0]), "s"(scA[8]));
+        const bool moreB = s + 1 < S;
+        load_scene(scp + (moreB ? 9 : 0), scB);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            loss_pixel_scene<NL, WITH_GRAD>(scA, x[v], y, mi[v], mt[v], eps, inv_count, lsum, acc[v]);
+        if (!moreB) break;
+        asm volatile("" ::"s"(scB[0]), "s"(scB[8]));
+        const bool moreA = s + 2 < S;
+        load_scene(scp + (moreA ? 18 : 9), scA);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            loss_pixel_scene<NL, WITH_GRAD>(scB, x[v], y, mi[v], mt[v], eps, inv_count, lsum, acc[v]);
+        if (!moreA) break;
+    }
+    return lsum;
+}
+
 template <int VEC, bool WITH_GRAD>
 __global__ __launch_bounds__(kThreads) void k_rendering_loss(const float *__restrict__ input,
                                                              const float *__restrict__ target,
                                                              const float *__restrict__ scenes,
                                                              const float *__restrict__ xrow, float eps,
-                                                             float inv_count, float *__restrict__ grad_input,
-                                                             float *__restrict__ partials, int S, int H, int W)
+                                                             float inv_count, double loss_scale, float fixed_scale,
+                                                             float *__restrict__ grad_input,
+                                                             unsigned long long *__restrict__ ws,
+                                                             float *__restrict__ loss_out, int S, int H, int W)
 {
     __shared__ float wave_part[kThreads / 64];
-    constexpr float kLn2 = 0.693147180559945309417f;
     const size_t plane = (size_t)H * W;
     const size_t pix = ((size_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
     const int b = blockIdx.y;
@@ -496,14 +635,21 @@ __global__ __launch_bounds__(kThreads) void k_rendering_loss(const float *__rest
     float lsum = 0.0f;
     if (active) {
         MapK mi[VEC], mt[VEC];
+        bool tied = true;
         {
             Maps m[VEC];
             load_maps<VEC>(input + (size_t)b * 12 * plane, plane, pix, m);
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) mi[v] = prepare<WITH_GRAD>(m[v]);
+            for (int v = 0; v < VEC; ++v) {
+                mi[v] = prepare<WITH_GRAD>(m[v]);
+                tied = tied && tied_roughness(m[v]);
+            }
             load_maps<VEC>(target + (size_t)b * 12 * plane, plane, pix, m);
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) mt[v] = prepare<false>(m[v]);
+            for (int v = 0; v < VEC; ++v) {
+                mt[v] = prepare<false>(m[v]);
+                tied = tied && tied_roughness(m[v]);
+            }
         }
         float x[VEC], y;
         pixel_coords<VEC>(xrow, pix, W, x, y);
@@ -511,44 +657,46 @@ __global__ __launch_bounds__(kThreads) void k_rendering_loss(const float *__rest
 #pragma unroll
         for (int v = 0; v < VEC; ++v) zero_grad(acc[v]);
         const float *__restrict__ scp = scenes + (size_t)b * S * 9;
-        float sc[9], sc_next[9];
-        load_scene(scp, sc_next);
-        for (int s = 0; s < S; ++s) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) sc[i] = sc_next[i];
-            // prefetch the next render's scalars (SGPRs) behind this iteration's arithmetic
-            scp += (s + 1 < S) ? 9 : 0;
-            load_scene(scp, sc_next);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const Geom g = geometry(sc, x[v], y);
-                Ctx ci, ct;
-                float ri[3], rt[3], g_rad[3];
-                shade<false>(g, mt[v], rt, ct);
-                shade<WITH_GRAD>(g, mi[v], ri, ci);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    // losses.py:46-50: |log(ri + eps) - log(rt + eps)|, v_log_f32 = log2
-                    const float ai = ri[k] + eps, at = rt[k] + eps;
-                    const float delta = kLn2 * (__builtin_amdgcn_logf(ai) - __builtin_amdgcn_logf(at));
-                    lsum += fabsf(delta);
-                    // d|delta|/d ri = sign(delta)/(N*ai), sign(0) = 0 as in torch
-                    const float sg = __builtin_amdgcn_fmed3f(delta * 1.0e30f, -1.0f, 1.0f);
-                    g_rad[k] = sg * (inv_count * rcp_(ai));
-                }
-                if (WITH_GRAD) shade_bwd(g, mi[v], ci, g_rad, acc[v]);
-            }
-        }
+        if (__all(tied))     // wave-uniform: every lane's input AND target roughness channels are tied
+            lsum = loss_scene_loop<VEC, 1, WITH_GRAD>(mi, mt, x, y, scp, S, eps, inv_count, acc);
+        else
+            lsum = loss_scene_loop<VEC, 3, WITH_GRAD>(mi, mt, x, y, scp, S, eps, inv_count, acc);
         if (WITH_GRAD) store_grads<VEC>(grad_input + (size_t)b * 12 * plane, plane, pix, acc);
     }
     lsum = wave_sum(lsum);
     if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = lsum;
+    __shared__ int finisher;
     __syncthreads();
     if (threadIdx.x == 0) {
+        finisher = 0;
         float t = 0.0f;
 #pragma unroll
         for (int w = 0; w < kThreads / 64; ++w) t += wave_part[w];
-        partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+        const unsigned nblocks = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned slot = bid & (kLossSlots - 1);
+        const unsigned slot_blocks = (nblocks - slot + kLossSlots - 1) / kLossSlots;
+        const unsigned long long fixed = (unsigned long long)(t * fixed_scale + 0.5f);   // < 2^48 by choice of scale
+        // device-scope returning atomic, performed at the memory side: add + arrival count in one
+        const unsigned long long old = atomicAdd(&ws[slot], (1ULL << kLossCountShift) | fixed);
+        if ((unsigned)(old >> kLossCountShift) + 1 == slot_blocks) {
+            const unsigned nslots = nblocks < (unsigned)kLossSlots ? nblocks : (unsigned)kLossSlots;
+            const unsigned long long ticket = atomicAdd(&ws[kLossSlots], 1ULL);
+            if (ticket + 1 == nslots) finisher = 1;
+        }
+    }
+    __syncthreads();
+    if (finisher && threadIdx.x < 64) {
+        // every slot is complete (its completer drew its ticket after its add had returned):
+        // one wave fetches-and-clears all slots in parallel, integer wave reduction
+        const unsigned nblocks = gridDim.x * gridDim.y;
+        unsigned long long v = 0;
+        if (threadIdx.x < (unsigned)kLossSlots && threadIdx.x < nblocks) v = atomicExch(&ws[threadIdx.x], 0ULL) & kLossSumMask;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (threadIdx.x == 0) {
+            atomicExch(&ws[kLossSlots], 0ULL);
+            loss_out[0] = (float)((double)v * loss_scale);
+        }
     }
 }
 
@@ -589,22 +737,6 @@ __global__ __launch_bounds__(kThreads) void k_check_arith(unsigned long long n, 
     }
     if (bad_div) atomicAdd(&counts[0], bad_div);
     if (bad_sqrt) atomicAdd(&counts[1], bad_sqrt);
-}
-
-// one workgroup: fixed-order fp64 sum of the per-workgroup partials -> mean
-__global__ __launch_bounds__(kThreads) void k_loss_finalize(const float *__restrict__ partials, int n,
-                                                            double inv_count, float *__restrict__ loss_out)
-{
-    __shared__ double red[kThreads];
-    double t = 0.0;
-    for (int i = threadIdx.x; i < n; i += kThreads) t += (double)partials[i];
-    red[threadIdx.x] = t;
-    __syncthreads();
-    for (int off = kThreads / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) loss_out[0] = (float)(red[0] * inv_count);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -723,9 +855,7 @@ int svbrdf_render_bwd(const float *maps, const float *scenes, const float *xrow,
 size_t svbrdf_rendering_loss_workspace_bytes(int B, int S, int H, int W)
 {
     if (B <= 0 || S <= 0 || H <= 0 || W <= 0) return 0;
-    // one fp32 partial per workgroup; sized for the narrowest vector width (most workgroups)
-    const dim3 g = grid_for(B, H, W, 1);
-    return (size_t)g.x * g.y * sizeof(float);
+    return (kLossSlots + 1) * sizeof(unsigned long long);   // sharded fixed-point accumulators + ticket
 }
 
 int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *target, const float *scenes,
@@ -737,7 +867,7 @@ int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *target, const
         return fail(SVBRDF_ERR_NULL, "rendering_loss: null pointer");
     if (int e = check_dims(B, S, H, W)) return e;
     if (!aligned(input, 4) || !aligned(target, 4) || !aligned(scenes, 4) || !aligned(xrow, 4) ||
-        !aligned(loss_out, 4) || !aligned(workspace, 4) || (grad_input && !aligned(grad_input, 4)))
+        !aligned(loss_out, 4) || !aligned(workspace, 8) || (grad_input && !aligned(grad_input, 4)))
         return fail(SVBRDF_ERR_ALIGN, "rendering_loss: pointers must be 4-byte aligned");
     if (workspace_bytes < svbrdf_rendering_loss_workspace_bytes(B, S, H, W))
         return fail(SVBRDF_ERR_WORKSPACE, "rendering_loss: workspace too small");
@@ -746,23 +876,33 @@ int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *target, const
     const dim3 grid = grid_for(B, H, W, vec), block(kThreads);
     const double count = (double)B * S * 3.0 * (double)H * (double)W;
     const float inv_count = (float)(1.0 / count);
-    float *partials = static_cast<float *>(workspace);
-#define SVBRDF_LAUNCH_K3(V)                                                                               \
-    do {                                                                                                  \
-        if (grad_input)                                                                                   \
-            hipLaunchKernelGGL((k_rendering_loss<V, true>), grid, block, 0, st, input, target, scenes,    \
-                               xrow, eps, inv_count, grad_input, partials, S, H, W);                      \
-        else                                                                                              \
-            hipLaunchKernelGGL((k_rendering_loss<V, false>), grid, block, 0, st, input, target, scenes,   \
-                               xrow, eps, inv_count, grad_input, partials, S, H, W);                      \
+    unsigned long long *ws = static_cast<unsigned long long *>(workspace);
+    // Fixed-point scale 2^k of the per-workgroup partial sums: as fine as 2^-24, coarser only if
+    // a slot could otherwise outgrow its 48 bits (|dlog| <= 32 per term is far beyond any
+    // radiance this renderer can produce: log(1e13/0.1)).
+    int k = 24;
+    const double worst_per_slot = count * 32.0 / (double)kLossSlots + 32.0 * kThreads * 4 * 3 * S;
+    while (k > 0 && worst_per_slot * std::ldexp(1.0, k) >= std::ldexp(1.0, kLossCountShift - 1)) --k;
+    const float fixed_scale = (float)std::ldexp(1.0, k);
+    const double loss_scale = std::ldexp(1.0, -k) / count;
+    if ((unsigned long long)grid.x * grid.y >= (1ULL << 16) * kLossSlots)
+        return fail(SVBRDF_ERR_DIMS, "rendering_loss: too many workgroups for the arrival counters");
+#define SVBRDF_LAUNCH_K3(V)                                                                                 \
+    do {                                                                                                    \
+        if (grad_input)                                                                                     \
+            hipLaunchKernelGGL((k_rendering_loss<V, true>), grid, block, 0, st, input, target, scenes,      \
+                               xrow, eps, inv_count, loss_scale, fixed_scale, grad_input, ws, loss_out,     \
+                               S, H, W);                                                                    \
+        else                                                                                                \
+            hipLaunchKernelGGL((k_rendering_loss<V, false>), grid, block, 0, st, input, target, scenes,     \
+                               xrow, eps, inv_count, loss_scale, fixed_scale, grad_input, ws, loss_out,     \
+                               S, H, W);                                                                    \
     } while (0)
     if (vec == 4) SVBRDF_LAUNCH_K3(4);
     else if (vec == 2) SVBRDF_LAUNCH_K3(2);
     else SVBRDF_LAUNCH_K3(1);
 #undef SVBRDF_LAUNCH_K3
-    if (int e = launch_status("rendering_loss launch")) return e;
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), block, 0, st, partials, (int)(grid.x * grid.y), 1.0 / count, loss_out);
-    return launch_status("loss_finalize launch");
+    return launch_status("rendering_loss launch");
 }
 
 int svbrdf_scale_inplace(float *data, const float *scale_dev, size_t n, void *stream)

@@ -126,9 +126,9 @@ class _Recorder:
         return np.stack([scene_table(s) for s in self.items])
 
 
-def g3_loss(name, B, H, seed, rng_seed, n_random=3, n_specular=6):
-    inp = synth.make_maps(seed, B, H, tiled_roughness=True)
-    tgt = synth.make_maps(seed + 1, B, H, tiled_roughness=True)
+def g3_loss(name, B, H, seed, rng_seed, n_random=3, n_specular=6, tiled=True):
+    inp = synth.make_maps(seed, B, H, tiled_roughness=tiled)
+    tgt = synth.make_maps(seed + 1, B, H, tiled_roughness=tiled)
     x = torch.from_numpy(inp).clone().requires_grad_(True)
     loss_fn = ref_losses.RenderingLoss(ref_renderers.LocalRenderer())
     loss_fn.random_configuration_count = n_random
@@ -293,11 +293,15 @@ def g9_kat():
 
 def main():
     torch.set_num_threads(max(1, os.cpu_count() or 1))
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-untied-loss":   # added after the first freeze
+        g3_loss("g3_loss_20_untied.npz", 2, 20, 141, 13, tiled=False)
+        return
     g1_render_64()
     g2_lattice(256, 8, 111)
     g2_lattice(512, 16, 112)
     g3_loss("g3_loss_48.npz", 2, 48, 121, 11)
     g3_loss("g3_loss_7_s5.npz", 3, 7, 131, 12, n_random=2, n_specular=3)
+    g3_loss("g3_loss_20_untied.npz", 2, 20, 141, 13, tiled=False)   # three independent roughness channels
     g4_edge_cases()
     g5_sampler()
     g6_linspace()

@@ -45,7 +45,7 @@ def test_kat_bit_exact(oracle, golden):
                                   np.array([0x3f86e35a, 0x3f588c83, 0x3f235253], dtype=np.uint32))
 
 
-@pytest.mark.parametrize("name", ["g3_loss_48.npz", "g3_loss_7_s5.npz"])
+@pytest.mark.parametrize("name", ["g3_loss_48.npz", "g3_loss_7_s5.npz", "g3_loss_20_untied.npz"])
 def test_rendering_loss_and_gradient(oracle, golden, name):
     g = golden(name)
     loss, grad = oracle.rendering_loss(g["input"], g["target"], g["scenes"])
