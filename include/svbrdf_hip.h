@@ -98,12 +98,12 @@ SVBRDF_API int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *ta
  * RenderingLoss.forward's scalar output) to grad_input. */
 SVBRDF_API int svbrdf_scale_inplace(float *data, const float *scale_dev, size_t n, void *stream);
 
-/* Test aid: evaluates the kernels' shared-reciprocal division and Newton square root
- * (the primitives that stand in for the reference's torch.div / torch.sqrt on the
- * ill-conditioned coords -> NH path) on n pseudo-random operands -- denominators
- * log-uniform in [lo, hi], numerators uniform in [-hi, hi] -- and ADDS the number of
- * results that differ from the IEEE-correct `/` and sqrtf to counts_dev[0] (division)
- * and counts_dev[1] (sqrt).  counts_dev: two zero-initialised device uint64. */
+/* Test aid: evaluates the kernels' Newton square root and shared-reciprocal division
+ * (the primitives that stand in for the reference's torch.sqrt / torch.div, i.e.
+ * normalize() of renderers.py:11-12, on the ill-conditioned coords -> NH path) on n
+ * pseudo-random operands -- squared lengths x log-uniform in [lo, hi], numerators a
+ * uniform in [-hi, hi] -- and ADDS the number of results that differ from the
+ * IEEE-correct a / sqrtf(x) to counts_dev[0] and from sqrtf(x) to counts_dev[1].  counts_dev: two zero-initialised device uint64. */
 SVBRDF_API int svbrdf_debug_check_arith(unsigned long long n, unsigned seed, float lo, float hi,
                                         unsigned long long *counts_dev, void *stream);
 

@@ -57,41 +57,33 @@ __device__ __forceinline__ float rsq_(float x) { return __builtin_amdgcn_rsqf(x)
 
 // Correctly rounded a/b for several numerators over ONE denominator: the reciprocal is
 // refined once (v_rcp + 2 FMA, Newton) and shared; each quotient then costs a multiply and
-// two exact-residual FMA corrections (Markstein).  Same result as the compiler's IEEE
-// division sequence (v_div_scale/v_div_fmas/v_div_fixup, ~11 instructions per quotient) for
+// one exact-residual FMA correction (Markstein).  The compiler's IEEE division sequence
+// (v_div_scale/v_div_fmas/v_div_fixup) costs ~11 instructions per quotient.  Valid for
 // operands away from the overflow/denormal range, which holds here: |a| <= ~1e3 and
-// 1e-3 <~ b <~ 1e3 (lengths of camera/light offsets).  svbrdf_debug_check_arith() measures
-// the agreement with the IEEE `/` on the device.
+// 1e-3 <~ b <~ 1e3 (lengths of camera/light offsets).  svbrdf_debug_check_arith() compares
+// both primitives with the IEEE-correct `/` and sqrtf on the device: 0 mismatches in
+// 3 x 2^31 operand pairs (tests/test_gpu_parity.py).
 struct Recip {
     float b, y;
 };
-__device__ __forceinline__ Recip make_recip(float b)
-{
-    const float y0 = rcp_(b);
-    const float e = fma_(-b, y0, 1.0f);
-    return Recip{b, fma_(e, y0, y0)};
-}
 __device__ __forceinline__ float div_rn(float a, const Recip &r)
 {
-    float q = a * r.y;
-    float e = fma_(-r.b, q, a);
-    q = fma_(e, r.y, q);
-    e = fma_(-r.b, q, a);
-    return fma_(e, r.y, q);
+    const float q = a * r.y;
+    return fma_(fma_(-r.b, q, a), r.y, q);
 }
 
-// Correctly rounded sqrt for x in the normal range (Markstein: rsq seed, one coupled
-// Newton step on (g ~ sqrt x, h ~ 1/(2 sqrt x)), final exact-residual correction).
-__device__ __forceinline__ float sqrt_rn(float x)
+// len = correctly rounded sqrt(x) for x in the normal range -- rsq seed y (1 ULP), g = x*y,
+// one exact-residual correction g + (x - g*g)*y/2 -- together with the refined reciprocal
+// of len (Newton step from the same seed, no extra v_rcp) for the divisions that follow.
+// `seed` returns y ~ 1/sqrt(x) for well-conditioned uses.
+__device__ __forceinline__ Recip length_rn(float x, float &seed)
 {
     const float y = rsq_(x);
-    float g = x * y;
-    float h = 0.5f * y;
-    const float r = fma_(-h, g, 0.5f);
-    g = fma_(g, r, g);
-    h = fma_(h, r, h);
-    const float d = fma_(-g, g, x);
-    return fma_(d, h, g);
+    const float g = x * y;
+    const float len = fma_(fma_(-g, g, x), 0.5f * y, g);
+    const float e = fma_(-len, y, 1.0f);
+    seed = y;
+    return Recip{len, fma_(e, y, y)};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -113,20 +105,20 @@ __device__ __forceinline__ Geom geometry(const float sc[9], float x, float y)
     Geom g;
     const float rcx = sc[0] - x, rcy = sc[1] - y, rcz = sc[2];   // z of the patch is 0
     const float rlx = sc[3] - x, rly = sc[4] - y, rlz = sc[5];
-    const float lc = sqrt_rn(dot3(rcx, rcy, rcz, rcx, rcy, rcz));
-    const float ll = sqrt_rn(dot3(rlx, rly, rlz, rlx, rly, rlz));
-    const Recip ic = make_recip(lc), il = make_recip(ll);
+    float yc, yl, yh;
+    const Recip ic = length_rn(dot3(rcx, rcy, rcz, rcx, rcy, rcz), yc);
+    const Recip il = length_rn(dot3(rlx, rly, rlz, rlx, rly, rlz), yl);
     g.wox = div_rn(rcx, ic); g.woy = div_rn(rcy, ic); g.woz = div_rn(rcz, ic);
     g.wix = div_rn(rlx, il); g.wiy = div_rn(rly, il); g.wiz = div_rn(rlz, il);
     const float sx = (g.wix + g.wox) * 0.5f, sy = (g.wiy + g.woy) * 0.5f, sz = (g.wiz + g.woz) * 0.5f;
-    const Recip ih = make_recip(sqrt_rn(dot3(sx, sy, sz, sx, sy, sz)));
+    const Recip ih = length_rn(dot3(sx, sy, sz, sx, sy, sz), yh);
     g.hx = div_rn(sx, ih); g.hy = div_rn(sy, ih); g.hz = div_rn(sz, ih);
     // from here on the computation is well conditioned: 1-ULP primitives are enough
     const float VH = fmaxf(dot3(g.wox, g.woy, g.woz, g.hx, g.hy, g.hz), kMinDot);
     const float t = 1.0f - VH;
     const float t2 = t * t;
     g.p = (t2 * t2) * t;
-    const float fall = rcp_(ll * ll);
+    const float fall = yl * yl;                       // 1/|L|^2 (renderers.py:99), rsq seed squared
 #pragma unroll
     for (int k = 0; k < 3; ++k) g.E[k] = sc[6 + k] * fall;
     return g;
@@ -731,9 +723,12 @@ __global__ __launch_bounds__(kThreads) void k_check_arith(unsigned long long n, 
         const float u0 = (float)(h0 >> 8) * (1.0f / 16777216.0f), u1 = (float)(h1 >> 8) * (1.0f / 16777216.0f);
         const float b = lo * exp2f(u0 * log2f(hi / lo));
         const float a = (2.0f * u1 - 1.0f) * hi;
-        const Recip r = make_recip(b);
-        if (div_rn(a, r) != a / b) ++bad_div;
-        if (sqrt_rn(b) != sqrtf(b)) ++bad_sqrt;
+        // b plays the squared length: the kernels divide by sqrt(b)
+        float seed;
+        const Recip r = length_rn(b, seed);
+        const float len = sqrtf(b);
+        if (r.b != len) ++bad_sqrt;
+        if (div_rn(a, r) != a / len) ++bad_div;
     }
     if (bad_div) atomicAdd(&counts[0], bad_div);
     if (bad_sqrt) atomicAdd(&counts[1], bad_sqrt);

@@ -107,8 +107,14 @@ class BatchSceneSampler:
         for b in range(B):
             self._draws.append((self._raw[b].uniform_, 0.0, 1.0))
             if M > 0:
-                self._draws.append((self._nrm[b, 0].normal_, 0.5, 0.75))
-                self._draws.append((self._nrm[b, 1].normal_, 0.5, 0.75))
+                if 2 * M < 16:
+                    # below 16 elements torch's CPU normal_ is the sequential scalar Box-Muller path
+                    # (its cached second sample lives in the generator), so ONE call over the 2M
+                    # contiguous slots draws exactly what the reference's two M-element calls draw
+                    self._draws.append((self._nrm[b].normal_, 0.5, 0.75))
+                else:
+                    self._draws.append((self._nrm[b, 0].normal_, 0.5, 0.75))
+                    self._draws.append((self._nrm[b, 1].normal_, 0.5, 0.75))
                 self._draws.append((self._shift_buf[b].uniform_, -1.0, 1.0))
 
     def sample(self):

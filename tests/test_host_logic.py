@@ -90,7 +90,7 @@ def test_scene_sampler_bit_exact_vs_reference(golden):
     assert torch.equal(env.scene_to_row(scenes[3]), torch.from_numpy(g["seed_7"][3]))
 
 
-@pytest.mark.parametrize("B,R,M", [(8, 3, 6), (2, 11, 21), (1, 3, 6), (5, 0, 4), (3, 2, 0), (2, 17, 40)])
+@pytest.mark.parametrize("B,R,M", [(8, 3, 6), (2, 11, 21), (1, 3, 6), (5, 0, 4), (3, 2, 0), (2, 17, 40), (3, 1, 7), (3, 1, 8)])
 def test_batch_sampler_equals_per_item_draws_and_rng_state(B, R, M):
     from svbrdf_estimation_amd import environment as env
     samp = env.BatchSceneSampler(B, R, M)

@@ -1,0 +1,42 @@
+"""Where does the host time of one bench step go?  (run on the GPU box)"""
+import cProfile, io, os, pstats, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from svbrdf_estimation_amd import _native, losses, renderers
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from k3_sweep import maps  # noqa
+
+dev = torch.device("cuda:0")
+gen = torch.Generator().manual_seed(1)
+inp = maps(8, 256, gen).to(dev).requires_grad_(True)
+tgt = maps(8, 256, gen).to(dev)
+fn = losses.RenderingLoss(renderers.LocalRenderer())
+
+def step():
+    inp.grad = None
+    loss = fn(inp, tgt)
+    loss.backward()
+
+def T(f, n=300):
+    for _ in range(30): f()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): f()
+    h = time.perf_counter() - t
+    torch.cuda.synchronize()
+    return h / n * 1e6, (time.perf_counter() - t) / n * 1e6
+
+print("step: host %.1f us, wall %.1f us" % T(step))
+table = fn.sample_scene_table(8)
+print("sample_scene_table: %.1f us" % T(lambda: fn.sample_scene_table(8))[0])
+print("table.to(dev): %.1f us" % T(lambda: table.to(dev, non_blocking=True))[0])
+td = table.to(dev)
+print("native.rendering_loss: host %.1f us wall %.1f" % T(lambda: _native.rendering_loss(inp.detach(), tgt, td)))
+def fb():
+    inp.grad = None
+    l = losses._FusedRenderingLoss.apply(inp, tgt, td, 0.1); l.backward()
+print("Function fwd+bwd: host %.1f us wall %.1f" % T(fb))
+print("torch.empty_like: %.1f us" % T(lambda: torch.empty_like(tgt))[0])
+pr = cProfile.Profile(); pr.enable()
+for _ in range(300): step()
+pr.disable(); torch.cuda.synchronize()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(18); print(s.getvalue()[:3500])

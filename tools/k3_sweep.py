@@ -21,18 +21,20 @@ def timeit(fn, n=30, warm=5):
     t = sorted(x.elapsed_time(y) for x, y in evs)
     return t[len(t) // 2] * 1e3
 
-dev = torch.device("cuda:0")
-gen = torch.Generator().manual_seed(1)
-if os.environ.get("SWEEP") == "short":
-    cfgs = [(8, 256, S, True, g) for S in (1, 4, 9, 18) for g in (True, False)]
-else:
-    cfgs = [(8, 256, S, tied, g) for S in (1, 2, 4, 9, 18) for tied in (True, False) for g in (True, False)]
-    cfgs += [(32, 256, 9, True, True), (2, 256, 9, True, True), (8, 512, 9, True, True), (8, 512, 32, True, True)]
-for (B, H, S, tied, grad) in cfgs:
-    inp, tgt = maps(B, H, gen, tied).to(dev), maps(B, H, gen, tied).to(dev)
-    torch.manual_seed(0)
-    table = environment.BatchSceneSampler(B, S // 3, S - S // 3).sample().to(dev)
-    us = timeit(lambda: _native.rendering_loss(inp, tgt, table, 0.1, want_grad=grad))
-    px = B * H * H
-    print("B=%-3d H=%-4d S=%-3d tied=%d grad=%d  %8.1f us  %7.2f ns/pixel  %6.3f ns/pixel-scene  alg %.0f GB/s" % (
-        B, H, S, tied, grad, us, us * 1e3 / px, us * 1e3 / px / S, (144 if grad else 96) * px / us / 1e3), flush=True)
+if __name__ == "__main__":
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(1)
+    if os.environ.get("SWEEP") == "short":
+        cfgs = [(8, 256, S, True, g) for S in (1, 4, 9, 18) for g in (True, False)]
+    else:
+        cfgs = [(8, 256, S, tied, g) for S in (1, 2, 4, 9, 18) for tied in (True, False) for g in (True, False)]
+        cfgs += [(32, 256, 9, True, True), (2, 256, 9, True, True), (8, 512, 9, True, True), (8, 512, 32, True, True)]
+    for (B, H, S, tied, grad) in cfgs:
+        inp, tgt = maps(B, H, gen, tied).to(dev), maps(B, H, gen, tied).to(dev)
+        torch.manual_seed(0)
+        table = environment.BatchSceneSampler(B, S // 3, S - S // 3).sample().to(dev)
+        us = timeit(lambda: _native.rendering_loss(inp, tgt, table, 0.1, want_grad=grad))
+        px = B * H * H
+        print("B=%-3d H=%-4d S=%-3d tied=%d grad=%d  %8.1f us  %7.2f ns/pixel  %6.3f ns/pixel-scene  alg %.0f GB/s" % (
+            B, H, S, tied, grad, us, us * 1e3 / px, us * 1e3 / px / S, (144 if grad else 96) * px / us / 1e3), flush=True)
+
