@@ -34,7 +34,8 @@
 
 namespace {
 
-constexpr int kThreads = 256;          // 4 waves of 64
+constexpr int kThreads = 256;          // 4 waves of 64 (K1, K2)
+constexpr int kLossThreads = 256;      // K3 workgroup; 64 and 128 measured no faster (profiles/r01_k3_sweep.txt)
 constexpr float kPi = 3.14159274101257324219f;  // float32(math.pi), renderers.py:20,27
 constexpr float kMinDot = 0.001f;      // renderers.py:48-52
 constexpr float kMinRough = 0.001f;    // renderers.py:87
@@ -609,8 +610,8 @@ __device__ __forceinline__ float loss_scene_loop(const MapK mi[VEC], const MapK 
     return lsum;
 }
 
-template <int VEC, bool WITH_GRAD>
-__global__ __launch_bounds__(kThreads) void k_rendering_loss(const float *__restrict__ input,
+template <int VEC, bool WITH_GRAD, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_rendering_loss(const float *__restrict__ input,
                                                              const float *__restrict__ target,
                                                              const float *__restrict__ scenes,
                                                              const float *__restrict__ xrow, float eps,
@@ -619,9 +620,9 @@ __global__ __launch_bounds__(kThreads) void k_rendering_loss(const float *__rest
                                                              unsigned long long *__restrict__ ws,
                                                              float *__restrict__ loss_out, int S, int H, int W)
 {
-    __shared__ float wave_part[kThreads / 64];
+    __shared__ float wave_part[THREADS / 64];
     const size_t plane = (size_t)H * W;
-    const size_t pix = ((size_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
+    const size_t pix = ((size_t)blockIdx.x * THREADS + threadIdx.x) * VEC;
     const int b = blockIdx.y;
     const bool active = pix < plane;
     float lsum = 0.0f;
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(kThreads) void k_rendering_loss(const float *__rest
         finisher = 0;
         float t = 0.0f;
 #pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) t += wave_part[w];
+        for (int w = 0; w < THREADS / 64; ++w) t += wave_part[w];
         const unsigned nblocks = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
         const unsigned slot = bid & (kLossSlots - 1);
         const unsigned slot_blocks = (nblocks - slot + kLossSlots - 1) / kLossSlots;
@@ -868,7 +869,10 @@ int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *target, const
         return fail(SVBRDF_ERR_WORKSPACE, "rendering_loss: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int vec = pick_vec(env_vec("SVBRDF_K3_VEC", 1), W, {input, target, xrow, grad_input});
-    const dim3 grid = grid_for(B, H, W, vec), block(kThreads);
+    const char *te = std::getenv("SVBRDF_K3_THREADS");
+    const int threads = (te && std::atoi(te) == 64) ? 64 : ((te && std::atoi(te) == 128) ? 128 : kLossThreads);
+    const long long per_block = (long long)threads * vec;
+    const dim3 grid((unsigned)(((long long)H * W + per_block - 1) / per_block), (unsigned)B, 1), block(threads);
     const double count = (double)B * S * 3.0 * (double)H * (double)W;
     const float inv_count = (float)(1.0 / count);
     unsigned long long *ws = static_cast<unsigned long long *>(workspace);
@@ -876,27 +880,32 @@ int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *target, const
     // a slot could otherwise outgrow its 48 bits (|dlog| <= 32 per term is far beyond any
     // radiance this renderer can produce: log(1e13/0.1)).
     int k = 24;
-    const double worst_per_slot = count * 32.0 / (double)kLossSlots + 32.0 * kThreads * 4 * 3 * S;
+    const double worst_per_slot = count * 32.0 / (double)kLossSlots + 32.0 * 256 * 4 * 3 * S;
     while (k > 0 && worst_per_slot * std::ldexp(1.0, k) >= std::ldexp(1.0, kLossCountShift - 1)) --k;
     const float fixed_scale = (float)std::ldexp(1.0, k);
     const double loss_scale = std::ldexp(1.0, -k) / count;
     if ((unsigned long long)grid.x * grid.y >= (1ULL << 16) * kLossSlots)
         return fail(SVBRDF_ERR_DIMS, "rendering_loss: too many workgroups for the arrival counters");
+#define SVBRDF_LAUNCH_K3B(V, G, T)                                                                          \
+    hipLaunchKernelGGL((k_rendering_loss<V, G, T>), grid, block, 0, st, input, target, scenes, xrow, eps,   \
+                       inv_count, loss_scale, fixed_scale, grad_input, ws, loss_out, S, H, W)
 #define SVBRDF_LAUNCH_K3(V)                                                                                 \
     do {                                                                                                    \
-        if (grad_input)                                                                                     \
-            hipLaunchKernelGGL((k_rendering_loss<V, true>), grid, block, 0, st, input, target, scenes,      \
-                               xrow, eps, inv_count, loss_scale, fixed_scale, grad_input, ws, loss_out,     \
-                               S, H, W);                                                                    \
-        else                                                                                                \
-            hipLaunchKernelGGL((k_rendering_loss<V, false>), grid, block, 0, st, input, target, scenes,     \
-                               xrow, eps, inv_count, loss_scale, fixed_scale, grad_input, ws, loss_out,     \
-                               S, H, W);                                                                    \
+        if (grad_input) {                                                                                   \
+            if (threads == 64) SVBRDF_LAUNCH_K3B(V, true, 64);                                              \
+            else if (threads == 128) SVBRDF_LAUNCH_K3B(V, true, 128);                                       \
+            else SVBRDF_LAUNCH_K3B(V, true, 256);                                                           \
+        } else {                                                                                            \
+            if (threads == 64) SVBRDF_LAUNCH_K3B(V, false, 64);                                             \
+            else if (threads == 128) SVBRDF_LAUNCH_K3B(V, false, 128);                                      \
+            else SVBRDF_LAUNCH_K3B(V, false, 256);                                                          \
+        }                                                                                                   \
     } while (0)
     if (vec == 4) SVBRDF_LAUNCH_K3(4);
     else if (vec == 2) SVBRDF_LAUNCH_K3(2);
     else SVBRDF_LAUNCH_K3(1);
 #undef SVBRDF_LAUNCH_K3
+#undef SVBRDF_LAUNCH_K3B
     return launch_status("rendering_loss launch");
 }
 
