@@ -92,6 +92,19 @@ SVBRDF_API int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *ta
                                   void *workspace, size_t workspace_bytes,
                                   int B, int S, int H, int W, void *stream);
 
+/* K3 with SVBRDFL1Loss folded in -- replaces MixedLoss.forward AND its backward
+ * (losses.py:54-63 = l1_weight * SVBRDFL1Loss (losses.py:7-19) + RenderingLoss):
+ *   loss_out[0] = l1_weight * [ mean|n_i-n_t| + mean|log(d_i+eps_l1)-log(d_t+eps_l1)|
+ *                               + mean|r_i-r_t| + mean|log(s_i+eps_l1)-log(s_t+eps_l1)| ]
+ *                 + rendering loss (as above)
+ * on the 24 planes the kernel reads anyway: zero extra HBM traffic.  Same scratch and
+ * conventions as svbrdf_rendering_loss_fwd_bwd.  Reference values: l1_weight 0.1,
+ * eps_l1 0.01, eps_render 0.1. */
+SVBRDF_API int svbrdf_mixed_loss_fwd_bwd(const float *input, const float *target, const float *scenes,
+                                         const float *xrow, float eps_render, float l1_weight, float eps_l1,
+                                         float *loss_out, float *grad_input, void *workspace,
+                                         size_t workspace_bytes, int B, int S, int H, int W, void *stream);
+
 /* data[i] *= scale_dev[0] for i < n, on the device and without a host sync; when the
  * scalar is exactly 1.0 the kernel exits without touching `data`.  Used by the autograd
  * wrapper to apply the upstream gradient of the loss (the chain rule through

@@ -110,3 +110,20 @@ def rendering_loss(input, target, scenes, eps=0.1, xrow=None, want_grad=True, f6
     if rc:
         raise RuntimeError("oracle rendering_loss rc=%d" % rc)
     return loss.value, grad
+
+
+def mixed_loss(input, target, scenes, l1_weight=0.1, eps=0.1, eps_l1=0.01, xrow=None, want_grad=True, f64=False):
+    """losses.py:54-63: l1_weight * SVBRDFL1Loss (losses.py:7-19) + RenderingLoss, explicit scenes."""
+    input, scenes, B, S, H, W = _dims(input, scenes)
+    target = _f32(target)
+    assert target.shape == input.shape
+    xrow = make_xrow(W) if xrow is None else _f32(xrow)
+    loss = ctypes.c_double(0.0)
+    grad = np.empty((B, 12, H, W), dtype=np.float64 if f64 else np.float32) if want_grad else None
+    fn = lib().svbrdf_oracle_mixed_loss_f64 if f64 else lib().svbrdf_oracle_mixed_loss
+    gp = _p(grad, _f64p if f64 else _f32p) if want_grad else None
+    rc = fn(_p(input), _p(target), _p(scenes), _p(xrow), ctypes.c_float(eps), ctypes.c_float(l1_weight),
+            ctypes.c_float(eps_l1), ctypes.byref(loss), gp, B, S, H, W)
+    if rc:
+        raise RuntimeError("oracle mixed_loss rc=%d" % rc)
+    return loss.value, grad

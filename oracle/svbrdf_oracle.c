@@ -121,7 +121,18 @@ EXPORT int svbrdf_oracle_rendering_loss(const float *input, const float *target,
                                         int B, int S, int H, int W)
 {
     int e = check_dims(B, S, H, W);
-    return e ? e : rendering_loss_f32(input, target, scenes, xrow, eps, loss_out, grad_input, B, S, H, W);
+    return e ? e : rendering_loss_f32(input, target, scenes, xrow, eps, 0.0f, 0.01f, loss_out, grad_input, B, S, H, W);
+}
+
+/* losses.py:54-63 MixedLoss = l1_weight * SVBRDFL1Loss + RenderingLoss */
+EXPORT int svbrdf_oracle_mixed_loss(const float *input, const float *target,
+                                    const float *scenes, const float *xrow, float eps,
+                                    float l1_weight, float eps_l1,
+                                    double *loss_out, float *grad_input,
+                                    int B, int S, int H, int W)
+{
+    int e = check_dims(B, S, H, W);
+    return e ? e : rendering_loss_f32(input, target, scenes, xrow, eps, l1_weight, eps_l1, loss_out, grad_input, B, S, H, W);
 }
 
 EXPORT int svbrdf_oracle_render_fwd_f64(const float *maps, const float *scenes, const float *xrow,
@@ -145,5 +156,15 @@ EXPORT int svbrdf_oracle_rendering_loss_f64(const float *input, const float *tar
                                             int B, int S, int H, int W)
 {
     int e = check_dims(B, S, H, W);
-    return e ? e : rendering_loss_f64(input, target, scenes, xrow, eps, loss_out, grad_input, B, S, H, W);
+    return e ? e : rendering_loss_f64(input, target, scenes, xrow, eps, 0.0f, 0.01f, loss_out, grad_input, B, S, H, W);
+}
+
+EXPORT int svbrdf_oracle_mixed_loss_f64(const float *input, const float *target,
+                                        const float *scenes, const float *xrow, float eps,
+                                        float l1_weight, float eps_l1,
+                                        double *loss_out, double *grad_input,
+                                        int B, int S, int H, int W)
+{
+    int e = check_dims(B, S, H, W);
+    return e ? e : rendering_loss_f64(input, target, scenes, xrow, eps, l1_weight, eps_l1, loss_out, grad_input, B, S, H, W);
 }

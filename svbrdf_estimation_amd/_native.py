@@ -68,6 +68,10 @@ def _load():
         lib.svbrdf_rendering_loss_workspace_bytes.restype = ctypes.c_size_t
         lib.svbrdf_rendering_loss_fwd_bwd.argtypes = (
             [_fp, _fp, _fp, _fp, ctypes.c_float, _fp, _fp, _fp, ctypes.c_size_t] + [ctypes.c_int] * 4 + [_fp])
+        lib.svbrdf_mixed_loss_fwd_bwd.argtypes = (
+            [_fp, _fp, _fp, _fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, ctypes.c_size_t]
+            + [ctypes.c_int] * 4 + [_fp])
+        lib.svbrdf_mixed_loss_fwd_bwd.restype = ctypes.c_int
         lib.svbrdf_scale_inplace.argtypes = [_fp, _fp, ctypes.c_size_t, _fp]
         lib.svbrdf_scale_inplace.restype = ctypes.c_int
         for name in ("svbrdf_make_xrow", "svbrdf_render_fwd", "svbrdf_render_bwd", "svbrdf_rendering_loss_fwd_bwd"):
@@ -167,8 +171,9 @@ def render_bwd(maps, scenes, grad_out):
     return grad
 
 
-def rendering_loss(input, target, scenes, eps=0.1, want_grad=True):
-    """K3: fused loss (+ d loss/d input).  Returns (loss [1] device tensor, grad or None)."""
+def rendering_loss(input, target, scenes, eps=0.1, want_grad=True, l1_weight=0.0, eps_l1=0.01):
+    """K3: fused rendering loss (+ d loss/d input); with l1_weight != 0 the SVBRDF L1 loss is folded
+    in (MixedLoss).  Returns (loss [1] device tensor, grad or None)."""
     _require_device_f32(input, "input")
     _require_device_f32(target, "target")
     _require_device_f32(scenes, "scenes")
@@ -188,13 +193,20 @@ def rendering_loss(input, target, scenes, eps=0.1, want_grad=True):
     with torch.cuda.device(input.device):
         if hook is not None:
             hook("begin")
-        rc = lib.svbrdf_rendering_loss_fwd_bwd(
-            input.data_ptr(), target.data_ptr(), scenes.data_ptr(), xr.data_ptr(),
-            ctypes.c_float(eps), loss.data_ptr(), grad.data_ptr() if want_grad else None,
-            ws.data_ptr(), ws.numel() * 8, B, S, H, W, _stream(input.device))
+        if l1_weight != 0.0:
+            rc = lib.svbrdf_mixed_loss_fwd_bwd(
+                input.data_ptr(), target.data_ptr(), scenes.data_ptr(), xr.data_ptr(),
+                ctypes.c_float(eps), ctypes.c_float(l1_weight), ctypes.c_float(eps_l1), loss.data_ptr(),
+                grad.data_ptr() if want_grad else None, ws.data_ptr(), ws.numel() * 8, B, S, H, W,
+                _stream(input.device))
+        else:
+            rc = lib.svbrdf_rendering_loss_fwd_bwd(
+                input.data_ptr(), target.data_ptr(), scenes.data_ptr(), xr.data_ptr(),
+                ctypes.c_float(eps), loss.data_ptr(), grad.data_ptr() if want_grad else None,
+                ws.data_ptr(), ws.numel() * 8, B, S, H, W, _stream(input.device))
         if hook is not None:
             hook("end")
-    _check(rc, "svbrdf_rendering_loss_fwd_bwd")
+    _check(rc, "svbrdf_mixed_loss_fwd_bwd" if l1_weight != 0.0 else "svbrdf_rendering_loss_fwd_bwd")
     return loss, grad
 
 

@@ -35,7 +35,7 @@
 namespace {
 
 constexpr int kThreads = 256;          // 4 waves of 64 (K1, K2)
-constexpr int kLossThreads = 256;      // K3 workgroup; 64 and 128 measured no faster (profiles/r01_k3_sweep.txt)
+constexpr int kLossThreads = 256;      // K3 workgroup; 64 and 128 threads measured no faster
 constexpr float kPi = 3.14159274101257324219f;  // float32(math.pi), renderers.py:20,27
 constexpr float kMinDot = 0.001f;      // renderers.py:48-52
 constexpr float kMinRough = 0.001f;    // renderers.py:87
@@ -575,86 +575,105 @@ __device__ __forceinline__ void loss_pixel_scene(const float sc[9], float x, flo
     if (WITH_GRAD) shade_bwd<NL>(g, mi, di, li, Fi, fi, g_rad, acc);
 }
 
-// Scene loop of K3, unrolled by two with the scene scalars double-buffered in SGPRs: the
-// scalar loads of render s+1 are issued before the arithmetic of render s (sched_barrier
-// keeps them there) so their latency never sits on the critical path.
-template <int VEC, int NL, bool WITH_GRAD>
-__device__ __forceinline__ float loss_scene_loop(const MapK mi[VEC], const MapK mt[VEC], const float x[VEC], float y,
+// Scene loop of K3, unrolled by two with the scene scalars double-buffered: the loads of
+// render s+1 are issued before the arithmetic of render s (sched_barrier keeps them there)
+// so their latency never sits on the critical path.
+template <int NL, bool WITH_GRAD>
+__device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt, float x, float y,
                                                  const float *__restrict__ scp, int S, float eps, float inv_count,
-                                                 Grad acc[VEC])
+                                                 Grad &acc)
 {
     float lsum = 0.0f;
     float scA[9], scB[9];
     load_scene(scp, scA);
     for (int s = 0;; s += 2, scp += 18) {
-        // Scalar loads return out of order, so a wait on them is always "all outstanding":
-        // consume the current buffer FIRST (the compiler puts its s_waitcnt here), only then
-        // issue the loads for the other buffer, and pin that order.
+        // A wait on these loads is placed by the compiler at the first use of the buffer:
+        // consume the current buffer FIRST, only then issue the loads for the other one.
         asm volatile("" ::"s"(scA[0]), "s"(scA[8]));
         const bool moreB = s + 1 < S;
         load_scene(scp + (moreB ? 9 : 0), scB);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v)
-            loss_pixel_scene<NL, WITH_GRAD>(scA, x[v], y, mi[v], mt[v], eps, inv_count, lsum, acc[v]);
+        loss_pixel_scene<NL, WITH_GRAD>(scA, x, y, mi, mt, eps, inv_count, lsum, acc);
         if (!moreB) break;
         asm volatile("" ::"s"(scB[0]), "s"(scB[8]));
         const bool moreA = s + 2 < S;
         load_scene(scp + (moreA ? 18 : 9), scA);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v)
-            loss_pixel_scene<NL, WITH_GRAD>(scB, x[v], y, mi[v], mt[v], eps, inv_count, lsum, acc[v]);
+        loss_pixel_scene<NL, WITH_GRAD>(scB, x, y, mi, mt, eps, inv_count, lsum, acc);
         if (!moreA) break;
     }
     return lsum;
 }
 
-template <int VEC, bool WITH_GRAD, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_rendering_loss(const float *__restrict__ input,
-                                                             const float *__restrict__ target,
-                                                             const float *__restrict__ scenes,
-                                                             const float *__restrict__ xrow, float eps,
-                                                             float inv_count, double loss_scale, float fixed_scale,
-                                                             float *__restrict__ grad_input,
-                                                             unsigned long long *__restrict__ ws,
-                                                             float *__restrict__ loss_out, int S, int H, int W)
+struct L1Params {       // SVBRDFL1Loss folded into the same pass (losses.py:7-19, 62-63)
+    float sum_scale;    // l1_weight * S: puts the L1 sums on the rendering loss's 1/(B S 3 H W) scale
+    float grad_scale;   // l1_weight / (B 3 H W)
+    float eps;          // 0.01, losses.py:13
+};
+
+// sign with sign(0) = 0 (torch.sign), times `scale`
+__device__ __forceinline__ float signed_scale(float delta, float scale)
 {
-    __shared__ float wave_part[THREADS / 64];
+    return __builtin_amdgcn_fmed3f(delta * 1.0e30f, -1.0f, 1.0f) * scale;
+}
+
+// One thread = one pixel (VEC = 1: the kernel is VALU-bound, wider loads measured no gain
+// and cost occupancy).  WITH_L1 adds SVBRDFL1Loss on the 24 values already in registers.
+template <bool WITH_GRAD, bool WITH_L1>
+__global__ __launch_bounds__(kLossThreads) void k_rendering_loss(const float *__restrict__ input,
+                                                                 const float *__restrict__ target,
+                                                                 const float *__restrict__ scenes,
+                                                                 const float *__restrict__ xrow, float eps,
+                                                                 float inv_count, double loss_scale, float fixed_scale,
+                                                                 L1Params l1, float *__restrict__ grad_input,
+                                                                 unsigned long long *__restrict__ ws,
+                                                                 float *__restrict__ loss_out, int S, int H, int W)
+{
+    __shared__ float wave_part[kLossThreads / 64];
+    constexpr float kLn2 = 0.693147180559945309417f;
     const size_t plane = (size_t)H * W;
-    const size_t pix = ((size_t)blockIdx.x * THREADS + threadIdx.x) * VEC;
+    const size_t pix = (size_t)blockIdx.x * kLossThreads + threadIdx.x;
     const int b = blockIdx.y;
     const bool active = pix < plane;
     float lsum = 0.0f;
     if (active) {
-        MapK mi[VEC], mt[VEC];
-        bool tied = true;
-        {
-            Maps m[VEC];
-            load_maps<VEC>(input + (size_t)b * 12 * plane, plane, pix, m);
+        Maps in[1], tg[1];
+        load_maps<1>(input + (size_t)b * 12 * plane, plane, pix, in);
+        load_maps<1>(target + (size_t)b * 12 * plane, plane, pix, tg);
+        Grad acc;
+        zero_grad(acc);
+        float l1sum = 0.0f;
+        if (WITH_L1) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                mi[v] = prepare<WITH_GRAD>(m[v]);
-                tied = tied && tied_roughness(m[v]);
-            }
-            load_maps<VEC>(target + (size_t)b * 12 * plane, plane, pix, m);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                mt[v] = prepare<false>(m[v]);
-                tied = tied && tied_roughness(m[v]);
+            for (int k = 0; k < 3; ++k) {
+                const float dn = in[0].n[k] - tg[0].n[k], dr = in[0].r[k] - tg[0].r[k];
+                const float adi = in[0].d[k] + l1.eps, adt = tg[0].d[k] + l1.eps;
+                const float asi = in[0].s[k] + l1.eps, ast = tg[0].s[k] + l1.eps;
+                const float dd = kLn2 * (__builtin_amdgcn_logf(adi) - __builtin_amdgcn_logf(adt));
+                const float ds = kLn2 * (__builtin_amdgcn_logf(asi) - __builtin_amdgcn_logf(ast));
+                l1sum += (fabsf(dn) + fabsf(dr)) + (fabsf(dd) + fabsf(ds));
+                if (WITH_GRAD) {
+                    acc.n[k] = signed_scale(dn, l1.grad_scale);
+                    acc.r[k] = signed_scale(dr, l1.grad_scale);
+                    acc.d[k] = signed_scale(dd, l1.grad_scale) * rcp_(adi);
+                    acc.s[k] = signed_scale(ds, l1.grad_scale) * rcp_(asi);
+                }
             }
         }
-        float x[VEC], y;
-        pixel_coords<VEC>(xrow, pix, W, x, y);
-        Grad acc[VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) zero_grad(acc[v]);
+        const bool tied = tied_roughness(in[0]) && tied_roughness(tg[0]);
+        const MapK mi = prepare<WITH_GRAD>(in[0]), mt = prepare<false>(tg[0]);
+        float x[1], y;
+        pixel_coords<1>(xrow, pix, W, x, y);
         const float *__restrict__ scp = scenes + (size_t)b * S * 9;
         if (__all(tied))     // wave-uniform: every lane's input AND target roughness channels are tied
-            lsum = loss_scene_loop<VEC, 1, WITH_GRAD>(mi, mt, x, y, scp, S, eps, inv_count, acc);
+            lsum = loss_scene_loop<1, WITH_GRAD>(mi, mt, x[0], y, scp, S, eps, inv_count, acc);
         else
-            lsum = loss_scene_loop<VEC, 3, WITH_GRAD>(mi, mt, x, y, scp, S, eps, inv_count, acc);
-        if (WITH_GRAD) store_grads<VEC>(grad_input + (size_t)b * 12 * plane, plane, pix, acc);
+            lsum = loss_scene_loop<3, WITH_GRAD>(mi, mt, x[0], y, scp, S, eps, inv_count, acc);
+        if (WITH_L1) lsum = fma_(l1sum, l1.sum_scale, lsum);
+        if (WITH_GRAD) {
+            const Grad out[1] = {acc};
+            store_grads<1>(grad_input + (size_t)b * 12 * plane, plane, pix, out);
+        }
     }
     lsum = wave_sum(lsum);
     if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = lsum;
@@ -664,7 +683,7 @@ __global__ __launch_bounds__(THREADS) void k_rendering_loss(const float *__restr
         finisher = 0;
         float t = 0.0f;
 #pragma unroll
-        for (int w = 0; w < THREADS / 64; ++w) t += wave_part[w];
+        for (int w = 0; w < kLossThreads / 64; ++w) t += wave_part[w];
         const unsigned nblocks = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
         const unsigned slot = bid & (kLossSlots - 1);
         const unsigned slot_blocks = (nblocks - slot + kLossSlots - 1) / kLossSlots;
@@ -854,59 +873,66 @@ size_t svbrdf_rendering_loss_workspace_bytes(int B, int S, int H, int W)
     return (kLossSlots + 1) * sizeof(unsigned long long);   // sharded fixed-point accumulators + ticket
 }
 
-int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *target, const float *scenes,
-                                  const float *xrow, float eps, float *loss_out, float *grad_input,
-                                  void *workspace, size_t workspace_bytes, int B, int S, int H, int W,
-                                  void *stream)
+static int loss_impl(const char *who, const float *input, const float *target, const float *scenes,
+                     const float *xrow, float eps, float l1_weight, float eps_l1, float *loss_out,
+                     float *grad_input, void *workspace, size_t workspace_bytes, int B, int S, int H, int W,
+                     void *stream)
 {
-    if (!input || !target || !scenes || !xrow || !loss_out || !workspace)
-        return fail(SVBRDF_ERR_NULL, "rendering_loss: null pointer");
+    if (!input || !target || !scenes || !xrow || !loss_out || !workspace) return fail(SVBRDF_ERR_NULL, who);
     if (int e = check_dims(B, S, H, W)) return e;
     if (!aligned(input, 4) || !aligned(target, 4) || !aligned(scenes, 4) || !aligned(xrow, 4) ||
         !aligned(loss_out, 4) || !aligned(workspace, 8) || (grad_input && !aligned(grad_input, 4)))
-        return fail(SVBRDF_ERR_ALIGN, "rendering_loss: pointers must be 4-byte aligned");
+        return fail(SVBRDF_ERR_ALIGN, "loss: pointers must be 4-byte aligned (workspace 8-byte)");
     if (workspace_bytes < svbrdf_rendering_loss_workspace_bytes(B, S, H, W))
-        return fail(SVBRDF_ERR_WORKSPACE, "rendering_loss: workspace too small");
+        return fail(SVBRDF_ERR_WORKSPACE, "loss: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int vec = pick_vec(env_vec("SVBRDF_K3_VEC", 1), W, {input, target, xrow, grad_input});
-    const char *te = std::getenv("SVBRDF_K3_THREADS");
-    const int threads = (te && std::atoi(te) == 64) ? 64 : ((te && std::atoi(te) == 128) ? 128 : kLossThreads);
-    const long long per_block = (long long)threads * vec;
-    const dim3 grid((unsigned)(((long long)H * W + per_block - 1) / per_block), (unsigned)B, 1), block(threads);
-    const double count = (double)B * S * 3.0 * (double)H * (double)W;
+    const long long plane = (long long)H * W;
+    const dim3 grid((unsigned)((plane + kLossThreads - 1) / kLossThreads), (unsigned)B, 1), block(kLossThreads);
+    const double count = (double)B * S * 3.0 * (double)plane;
     const float inv_count = (float)(1.0 / count);
     unsigned long long *ws = static_cast<unsigned long long *>(workspace);
     // Fixed-point scale 2^k of the per-workgroup partial sums: as fine as 2^-24, coarser only if
     // a slot could otherwise outgrow its 48 bits (|dlog| <= 32 per term is far beyond any
     // radiance this renderer can produce: log(1e13/0.1)).
     int k = 24;
-    const double worst_per_slot = count * 32.0 / (double)kLossSlots + 32.0 * 256 * 4 * 3 * S;
+    const double l1_share = 1.0 + 4.0 * std::fabs((double)l1_weight);
+    const double worst_per_slot = (count * 32.0 / (double)kLossSlots + 32.0 * kLossThreads * 3 * S) * l1_share;
     while (k > 0 && worst_per_slot * std::ldexp(1.0, k) >= std::ldexp(1.0, kLossCountShift - 1)) --k;
     const float fixed_scale = (float)std::ldexp(1.0, k);
     const double loss_scale = std::ldexp(1.0, -k) / count;
     if ((unsigned long long)grid.x * grid.y >= (1ULL << 16) * kLossSlots)
-        return fail(SVBRDF_ERR_DIMS, "rendering_loss: too many workgroups for the arrival counters");
-#define SVBRDF_LAUNCH_K3B(V, G, T)                                                                          \
-    hipLaunchKernelGGL((k_rendering_loss<V, G, T>), grid, block, 0, st, input, target, scenes, xrow, eps,   \
-                       inv_count, loss_scale, fixed_scale, grad_input, ws, loss_out, S, H, W)
-#define SVBRDF_LAUNCH_K3(V)                                                                                 \
-    do {                                                                                                    \
-        if (grad_input) {                                                                                   \
-            if (threads == 64) SVBRDF_LAUNCH_K3B(V, true, 64);                                              \
-            else if (threads == 128) SVBRDF_LAUNCH_K3B(V, true, 128);                                       \
-            else SVBRDF_LAUNCH_K3B(V, true, 256);                                                           \
-        } else {                                                                                            \
-            if (threads == 64) SVBRDF_LAUNCH_K3B(V, false, 64);                                             \
-            else if (threads == 128) SVBRDF_LAUNCH_K3B(V, false, 128);                                      \
-            else SVBRDF_LAUNCH_K3B(V, false, 256);                                                          \
-        }                                                                                                   \
-    } while (0)
-    if (vec == 4) SVBRDF_LAUNCH_K3(4);
-    else if (vec == 2) SVBRDF_LAUNCH_K3(2);
-    else SVBRDF_LAUNCH_K3(1);
+        return fail(SVBRDF_ERR_DIMS, "loss: too many workgroups for the arrival counters");
+    const L1Params l1{l1_weight * (float)S, (float)((double)l1_weight / ((double)B * 3.0 * (double)plane)), eps_l1};
+#define SVBRDF_LAUNCH_K3(G, L)                                                                              \
+    hipLaunchKernelGGL((k_rendering_loss<G, L>), grid, block, 0, st, input, target, scenes, xrow, eps,      \
+                       inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, S, H, W)
+    if (l1_weight != 0.0f) {
+        if (grad_input) SVBRDF_LAUNCH_K3(true, true);
+        else SVBRDF_LAUNCH_K3(false, true);
+    } else {
+        if (grad_input) SVBRDF_LAUNCH_K3(true, false);
+        else SVBRDF_LAUNCH_K3(false, false);
+    }
 #undef SVBRDF_LAUNCH_K3
-#undef SVBRDF_LAUNCH_K3B
-    return launch_status("rendering_loss launch");
+    return launch_status(who);
+}
+
+int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *target, const float *scenes,
+                                  const float *xrow, float eps, float *loss_out, float *grad_input,
+                                  void *workspace, size_t workspace_bytes, int B, int S, int H, int W,
+                                  void *stream)
+{
+    return loss_impl("rendering_loss", input, target, scenes, xrow, eps, 0.0f, 0.01f, loss_out, grad_input,
+                     workspace, workspace_bytes, B, S, H, W, stream);
+}
+
+int svbrdf_mixed_loss_fwd_bwd(const float *input, const float *target, const float *scenes, const float *xrow,
+                              float eps_render, float l1_weight, float eps_l1, float *loss_out,
+                              float *grad_input, void *workspace, size_t workspace_bytes, int B, int S, int H,
+                              int W, void *stream)
+{
+    return loss_impl("mixed_loss", input, target, scenes, xrow, eps_render, l1_weight, eps_l1, loss_out,
+                     grad_input, workspace, workspace_bytes, B, S, H, W, stream);
 }
 
 int svbrdf_scale_inplace(float *data, const float *scale_dev, size_t n, void *stream)

@@ -33,14 +33,16 @@ class _FusedRenderingLoss(torch.autograd.Function):
     """K3 behind autograd: the kernel already produces d loss/d input for upstream grad 1."""
 
     @staticmethod
-    def forward(ctx, input, target, scenes, eps):
+    def forward(ctx, input, target, scenes, eps, l1_weight=0.0, eps_l1=0.01):
         need_in = ctx.needs_input_grad[0]
         need_tg = ctx.needs_input_grad[1]
-        loss, grad_in = _native.rendering_loss(input, target, scenes, eps, want_grad=need_in)
+        loss, grad_in = _native.rendering_loss(input, target, scenes, eps, want_grad=need_in,
+                                               l1_weight=l1_weight, eps_l1=eps_l1)
         grad_tg = None
         if need_tg:
-            # |log a - log b| is symmetric: the target's gradient is the same kernel with roles swapped
-            _, grad_tg = _native.rendering_loss(target, input, scenes, eps, want_grad=True)
+            # every term is |g(a) - g(b)|, symmetric: the target's gradient is the same kernel, roles swapped
+            _, grad_tg = _native.rendering_loss(target, input, scenes, eps, want_grad=True,
+                                                l1_weight=l1_weight, eps_l1=eps_l1)
         ctx.grads = (grad_in, grad_tg)
         return loss.view(())
 
@@ -57,7 +59,12 @@ class _FusedRenderingLoss(torch.autograd.Function):
         for g in (grad_in, grad_tg):
             if g is not None:
                 _native.scale_inplace_(g, scale)
-        return grad_in, grad_tg, None, None
+        return grad_in, grad_tg, None, None, None, None
+
+
+def _check_shapes(input, target):
+    if input.dim() != 4 or input.shape != target.shape or input.shape[1] != 12:
+        raise ValueError("input and target must both be [B,12,H,W]")
 
 
 class RenderingLoss(nn.Module):
@@ -77,17 +84,23 @@ class RenderingLoss(nn.Module):
         return self._sampler.sample()
 
     def forward(self, input, target):
-        if input.dim() != 4 or input.shape != target.shape:
-            raise ValueError("input and target must both be [B,12,H,W]")
-        if isinstance(self.renderer, renderers.LocalRenderer):
-            table = self.sample_scene_table(input.shape[0])
-            if not input.is_cuda:
-                raise _native.NativeLibraryError(
-                    "RenderingLoss with the MI355X LocalRenderer needs tensors on a ROCm device "
-                    "(got %s); there is no CPU fallback" % input.device)
-            return _FusedRenderingLoss.apply(input, target, table.to(input.device, non_blocking=True),
-                                             self.epsilon_render)
+        if self.uses_fused_kernel():
+            return self._forward_fused(input, target)
+        _check_shapes(input, target)
         return self._forward_plugin(input, target)
+
+    def uses_fused_kernel(self):
+        return isinstance(self.renderer, renderers.LocalRenderer)
+
+    def _forward_fused(self, input, target, l1_weight=0.0, eps_l1=0.01):
+        _check_shapes(input, target)
+        table = self.sample_scene_table(input.shape[0])
+        if not input.is_cuda:
+            raise _native.NativeLibraryError(
+                "RenderingLoss with the MI355X LocalRenderer needs tensors on a ROCm device "
+                "(got %s); there is no CPU fallback" % input.device)
+        return _FusedRenderingLoss.apply(input, target, table.to(input.device, non_blocking=True),
+                                         self.epsilon_render, float(l1_weight), float(eps_l1))
 
     def _forward_plugin(self, input, target):
         """Generic plugin path for a foreign renderer object (losses.py:29-52 semantics)."""
@@ -103,7 +116,11 @@ class RenderingLoss(nn.Module):
 
 
 class MixedLoss(nn.Module):
-    """losses.py:54-63: l1_weight * SVBRDFL1Loss + RenderingLoss."""
+    """losses.py:54-63: l1_weight * SVBRDFL1Loss + RenderingLoss.
+
+    With this package's ``LocalRenderer`` the L1 terms are folded into the fused kernel (the 24
+    map planes are already in registers: no extra HBM traffic, no extra launches) instead of
+    ~45 small elementwise launches of stock ops; any other renderer takes the literal sum."""
 
     def __init__(self, renderer, l1_weight=0.1):
         super().__init__()
@@ -112,4 +129,7 @@ class MixedLoss(nn.Module):
         self.rendering_loss = RenderingLoss(renderer)
 
     def forward(self, input, target):
+        if self.rendering_loss.uses_fused_kernel() and input.is_cuda and float(self.l1_weight) != 0.0:
+            return self.rendering_loss._forward_fused(input, target, l1_weight=float(self.l1_weight),
+                                                      eps_l1=self.l1_loss.epsilon_l1)
         return self.l1_weight * self.l1_loss(input, target) + self.rendering_loss(input, target)

@@ -184,8 +184,9 @@ def test_rendering_loss_golden(dev, native, oracle, golden, name):
     ref_l, ref_g = oracle.rendering_loss(g["input"], g["target"], g["scenes"])
     assert_loss_close(loss.item(), ref_l, name + " vs oracle")
     assert_loss_close(loss.item(), g["loss"], name + " vs reference", rtol=2e-6)
-    assert_grad_close(_np(grad), ref_g, name + " grad vs oracle")
-    assert_grad_close(_np(grad), g["grad_input"], name + " grad vs reference")
+    _, g64 = oracle.rendering_loss(g["input"], g["target"], g["scenes"], f64=True)
+    assert_grad_close(_np(grad), ref_g, name + " grad vs oracle", f64=g64)
+    assert_grad_close(_np(grad), g["grad_input"], name + " grad vs reference", f64=g64)
     loss_fwd, none = native.rendering_loss(_t(g["input"], dev), _t(g["target"], dev), _t(g["scenes"], dev), want_grad=False)
     assert none is None and loss_fwd.item() == loss.item()
 
@@ -236,15 +237,50 @@ def test_rendering_loss_module_reproduces_reference_with_same_seed(dev, golden):
     (2.0 * loss).backward()
     assert_loss_close(loss.item(), g["loss"], "module loss", rtol=2e-6)
     assert_grad_close(_np(x.grad) / 2.0, g["grad_input"], "module grad (upstream grad 2)")
-    # MixedLoss = 0.1 * L1 + rendering (losses.py:54-63)
+    # MixedLoss = 0.1 * L1 + rendering (losses.py:54-63): fused path, and target gradient by symmetry
     x2 = _t(g["input"], dev).requires_grad_(True)
+    t2 = _t(g["target"], dev).requires_grad_(True)
     torch.manual_seed(int(g["rng_seed"]))
-    mixed = losses.MixedLoss(renderers.LocalRenderer())(x2, _t(g["target"], dev))
+    mfn = losses.MixedLoss(renderers.LocalRenderer())
+    mixed = mfn(x2, t2)
     mixed.backward()
     assert_loss_close(mixed.item(), g["mixed_loss"], "mixed", rtol=2e-6)
     assert_grad_close(_np(x2.grad), g["mixed_grad"], "mixed grad")
+    from oracle import c_oracle
+    _, gt = c_oracle.mixed_loss(g["target"], g["input"], g["scenes"], 0.1)
+    _, gt64 = c_oracle.mixed_loss(g["target"], g["input"], g["scenes"], 0.1, f64=True)
+    assert_grad_close(_np(t2.grad), gt, "mixed target grad", f64=gt64)
+    # l1_weight = 0 degenerates to the rendering loss; the literal (unfused) sum agrees too
+    mfn0 = losses.MixedLoss(renderers.LocalRenderer(), l1_weight=0.0)
+    torch.manual_seed(int(g["rng_seed"]))
+    assert_loss_close(mfn0(_t(g["input"], dev), _t(g["target"], dev)).item(), g["loss"], "mixed w=0", rtol=2e-6)
+    torch.manual_seed(int(g["rng_seed"]))
+    literal = 0.1 * mfn.l1_loss(_t(g["input"], dev), _t(g["target"], dev)) + mfn.rendering_loss(
+        _t(g["input"], dev), _t(g["target"], dev))
+    assert_loss_close(literal.item(), mixed.item(), "fused vs literal sum", rtol=2e-6)
     l1 = losses.SVBRDFL1Loss()(_t(g["input"], dev), _t(g["target"], dev))
     assert_loss_close(l1.item(), g["l1_loss"], "l1", rtol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["g3_loss_48.npz", "g3_loss_7_s5.npz", "g3_loss_20_untied.npz"])
+def test_mixed_loss_fused_golden(dev, native, oracle, golden, name):
+    """MixedLoss = 0.1 * SVBRDFL1Loss + RenderingLoss in ONE kernel, vs oracle and reference fixture"""
+    g = golden(name)
+    d_in, d_tg, d_sc = _t(g["input"], dev), _t(g["target"], dev), _t(g["scenes"], dev)
+    loss, grad = native.rendering_loss(d_in, d_tg, d_sc, l1_weight=0.1, eps_l1=0.01)
+    ref_l, ref_g = oracle.mixed_loss(g["input"], g["target"], g["scenes"], 0.1)
+    assert_loss_close(loss.item(), ref_l, name + " vs oracle")
+    assert_loss_close(loss.item(), g["mixed_loss"], name + " vs reference", rtol=2e-6)
+    _, g64 = oracle.mixed_loss(g["input"], g["target"], g["scenes"], 0.1, f64=True)
+    assert_grad_close(_np(grad), ref_g, name + " grad vs oracle", f64=g64)
+    assert_grad_close(_np(grad), g["mixed_grad"], name + " grad vs reference", f64=g64)
+    # the L1 part alone (weight 1, rendering loss subtracted) against the reference's SVBRDFL1Loss
+    l_w1, _ = native.rendering_loss(d_in, d_tg, d_sc, l1_weight=1.0, want_grad=False)
+    l_w0, _ = native.rendering_loss(d_in, d_tg, d_sc, want_grad=False)
+    assert abs((l_w1.item() - l_w0.item()) - float(g["l1_loss"])) <= 3e-6 * float(g["l1_loss"])
+    # identical maps: exactly zero, gradient exactly zero
+    l0, g0 = native.rendering_loss(d_in, d_in.clone(), d_sc, l1_weight=0.1)
+    assert l0.item() == 0.0 and not g0.any().item()
 
 
 def test_rendering_loss_custom_scene_counts_and_target_grad(dev, oracle, golden):

@@ -62,6 +62,19 @@ def test_rendering_loss_and_gradient(oracle, golden, name):
     assert abs(loss - loss64) <= 2e-7 * abs(loss64)
 
 
+@pytest.mark.parametrize("name", ["g3_loss_48.npz", "g3_loss_7_s5.npz", "g3_loss_20_untied.npz"])
+def test_mixed_loss_and_gradient(oracle, golden, name):
+    """losses.py:54-63 MixedLoss and losses.py:7-19 SVBRDFL1Loss against the reference's values"""
+    g = golden(name)
+    loss, grad = oracle.mixed_loss(g["input"], g["target"], g["scenes"], 0.1)
+    assert_loss_close(loss, g["mixed_loss"], name)
+    assert_grad_close(grad, g["mixed_grad"], name + " mixed grad")
+    l1, gl1 = oracle.mixed_loss(g["input"], g["target"], g["scenes"], 1.0)
+    r, gr = oracle.rendering_loss(g["input"], g["target"], g["scenes"])
+    assert_loss_close(l1 - r, g["l1_loss"], name + " l1")
+    assert_grad_close(gl1 - gr, g["l1_grad"], name + " l1 grad")
+
+
 def test_edge_cases(oracle, golden):
     g = golden("g4_edge_cases.npz")
     for name in g["names"]:

@@ -15,7 +15,12 @@ Renderings, fp32, identical inputs:
   the reference's own deviation from the fp64 value is ~1e-4 relative.  The extra term
   admits exactly that: disagreement no larger than the reference's own rounding error.
 
-Gradients:  |a-b| <= 1e-4*|b| + 1e-5*max|b|   
+Gradients:  |a-b| <= 1e-4*|b| + 1e-5*max|b|   (SURVEY 8c).  The gradient contains 1/den^3
+            terms, so at the same highlight pixels ANY fp32 evaluation -- the reference's
+            autograd, the C oracle, the HIP kernels -- sits ~1e-4*max away from the fp64 gradient
+            (measured: oracle32 vs f64 and reference vs f64 both 1.1e-4*max on g3_loss_48).
+            Where an fp64 gradient is passed (`f64=`), the bound is widened per element by
+            2*|b - f64|, i.e. by the comparison value's own rounding error, as for renderings.
 Loss:       relative <= 1e-6
 """
 import numpy as np
@@ -54,8 +59,12 @@ def assert_render_vs_reference(a, ref, f64, what="rendering", scale=None):
     assert bad == 0, "%s: %d pixels differ by more than the reference's own rounding error" % (what, bad)
 
 
-def assert_grad_close(a, b, what="gradient", rtol=GRAD_RTOL, afrac=GRAD_ATOL_FRAC):
-    err, tol, scale = _viol(a, b, rtol, afrac)
+def assert_grad_close(a, b, what="gradient", rtol=GRAD_RTOL, afrac=GRAD_ATOL_FRAC, f64=None):
+    extra = None if f64 is None else 2.0 * np.abs(np.asarray(b, np.float64) - np.asarray(f64, np.float64))
+    err, tol, scale = _viol(a, b, rtol, afrac, extra=extra)
+    if f64 is not None:    # the widened bound may only be needed for a handful of elements
+        strict_ok = float((err <= rtol * np.abs(np.asarray(b, np.float64)) + afrac * scale).mean())
+        assert strict_ok >= 0.999, "%s: only %.4f%% of elements within the strict bound" % (what, 100 * strict_ok)
     bad = int((err > tol).sum())
     assert bad == 0, "%s: %d/%d outside %.0e rel + %.0e*max (max err/max %.3e)" % (
         what, bad, err.size, rtol, afrac, err.max() / max(scale, 1e-30))
