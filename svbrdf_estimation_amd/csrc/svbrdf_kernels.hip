@@ -87,6 +87,26 @@ __device__ __forceinline__ Recip length_rn(float x, float &seed)
     return Recip{len, fma_(e, y, y)};
 }
 
+// Measured on gfx950 (tools/valu_bank.hip): a VALU instruction with an SGPR or 32-bit literal
+// source issues ~1.75x slower than the same instruction on VGPR sources.  The handful of
+// constants the inner loop uses over and over therefore live in VGPRs (the empty asm makes
+// them opaque so the compiler cannot fold them back into literals).
+struct VConst {
+    float tiny;     // 0.001: the clamps of renderers.py:26, 48-52, 87
+    float pi, inv_pi;
+    float ln2;
+    float huge;     // 1e30, for sign()
+};
+__device__ __forceinline__ float vreg(float c)
+{
+    asm volatile("" : "+v"(c));
+    return c;
+}
+__device__ __forceinline__ VConst make_vconst()
+{
+    return VConst{vreg(kMinDot), vreg(kPi), vreg(1.0f / kPi), vreg(0.693147180559945309417f), vreg(1.0e30f)};
+}
+
 // ------------------------------------------------------------------------------------------
 // per-pixel device code
 // ------------------------------------------------------------------------------------------
@@ -101,7 +121,7 @@ struct Geom {           // map-independent, shared by input and target and by th
 
 // renderers.py:73-82, 91-93, 45, 49, 99.  `sc` (9 floats) is wave-uniform.  Everything up to
 // h reproduces the reference's rounding sequence exactly (see the header of this file).
-__device__ __forceinline__ Geom geometry(const float sc[9], float x, float y)
+__device__ __forceinline__ Geom geometry(const VConst &K, const float sc[9], float x, float y)
 {
     Geom g;
     const float rcx = sc[0] - x, rcy = sc[1] - y, rcz = sc[2];   // z of the patch is 0
@@ -115,7 +135,7 @@ __device__ __forceinline__ Geom geometry(const float sc[9], float x, float y)
     const Recip ih = length_rn(dot3(sx, sy, sz, sx, sy, sz), yh);
     g.hx = div_rn(sx, ih); g.hy = div_rn(sy, ih); g.hz = div_rn(sz, ih);
     // from here on the computation is well conditioned: 1-ULP primitives are enough
-    const float VH = fmaxf(dot3(g.wox, g.woy, g.woz, g.hx, g.hy, g.hz), kMinDot);
+    const float VH = fmaxf(dot3(g.wox, g.woy, g.woz, g.hx, g.hy, g.hz), K.tiny);
     const float t = 1.0f - VH;
     const float t2 = t * t;
     g.p = (t2 * t2) * t;
@@ -175,14 +195,14 @@ struct Dots {           // clamped dot products of one (pixel, scene, map set) a
 
 // renderers.py:48-52, 96.  The three dot products and 1-NH^2 follow the reference's
 // rounding exactly; everything derived from them is well conditioned (v_rcp, 1 ULP).
-__device__ __forceinline__ Dots dots(const Geom &g, const MapK &m)
+__device__ __forceinline__ Dots dots(const VConst &K, const Geom &g, const MapK &m)
 {
     Dots d;
     d.nh_raw = dot3(m.n[0], m.n[1], m.n[2], g.hx, g.hy, g.hz);
     d.vn_raw = dot3(g.wox, g.woy, g.woz, m.n[0], m.n[1], m.n[2]);
     d.ln_raw = dot3(g.wix, g.wiy, g.wiz, m.n[0], m.n[1], m.n[2]);
-    d.NH = fmaxf(d.nh_raw, kMinDot);
-    const float VN = fmaxf(d.vn_raw, kMinDot), LN = fmaxf(d.ln_raw, kMinDot);
+    d.NH = fmaxf(d.nh_raw, K.tiny);
+    const float VN = fmaxf(d.vn_raw, K.tiny), LN = fmaxf(d.ln_raw, K.tiny);
     d.LNp = fmaxf(d.ln_raw, 0.0f);
     d.NH2 = d.NH * d.NH;
     d.oN = 1.0f - d.NH2;
@@ -204,7 +224,7 @@ struct Lobe {
 };
 
 template <bool BWD>
-__device__ __forceinline__ Lobe lobe(float A, const Dots &d)
+__device__ __forceinline__ Lobe lobe(const VConst &K, float A, const Dots &d)
 {
     Lobe l;
     const float xV = fma_(A, d.uV, 1.0f), xL = fma_(A, d.uL, 1.0f);
@@ -215,8 +235,8 @@ __device__ __forceinline__ Lobe lobe(float A, const Dots &d)
     const float aV = 1.0f + wV, aL = 1.0f + wL;
     const float M = aV * aL;                            // 4/G
     const float den_raw = fma_(d.NH2, A, d.oN);
-    const float den = fmaxf(den_raw, kMinDen);          // renderers.py:26 clamp
-    const float pd = kPi * den;
+    const float den = fmaxf(den_raw, K.tiny);           // renderers.py:26 clamp
+    const float pd = K.pi * den;
     const float Q = pd * den;                           // A/D
     const float R = rcp_(M * Q);
     l.GD = A * R;
@@ -226,7 +246,7 @@ __device__ __forceinline__ Lobe lobe(float A, const Dots &d)
         const float KxV = hGD * ((RQ * aL) * iwV);      // dGD/dxV = -GD/(2 wV (1+wV))
         const float KxL = hGD * ((RQ * aV) * iwL);
         // dGD/dden = -2 GD/den, 1/den = (R M) pd; zero where the clamp is active
-        const float Kden = (den_raw >= kMinDen) ? (-2.0f * l.GD) * ((R * M) * pd) : 0.0f;
+        const float Kden = (den_raw >= K.tiny) ? (-2.0f * l.GD) * ((R * M) * pd) : 0.0f;
         l.KA = fma_(KxV, d.uV, fma_(KxL, d.uL, fma_(Kden, d.NH2, R)));
         l.KV = KxV * A;
         l.KL = KxL * A;
@@ -238,11 +258,11 @@ __device__ __forceinline__ Lobe lobe(float A, const Dots &d)
 // radiance of one pixel under one scene: renderers.py:43-65, 95-100.  NL = 3: one lobe per
 // colour channel (independent roughness channels); NL = 1: tied roughness, one lobe.
 template <int NL, bool BWD>
-__device__ __forceinline__ void shade(const Geom &g, const MapK &m, const Dots &d, Lobe lb[NL],
+__device__ __forceinline__ void shade(const VConst &K, const Geom &g, const MapK &m, const Dots &d, Lobe lb[NL],
                                       float F[3], float f[3], float rad[3])
 {
 #pragma unroll
-    for (int l = 0; l < NL; ++l) lb[l] = lobe<BWD>(m.A[l], d);
+    for (int l = 0; l < NL; ++l) lb[l] = lobe<BWD>(K, m.A[l], d);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         F[k] = fma_(m.oms[k], g.p, m.s[k]);                               // Schlick, renderers.py:29-32
@@ -255,11 +275,11 @@ __device__ __forceinline__ void shade(const Geom &g, const MapK &m, const Dots &
 // adjoint of shade() with PyTorch's sub-gradient conventions: clamp(min=m) passes the
 // gradient iff x >= m (inclusive); xi() has zero gradient (renderers.py:15-16).
 template <int NL>
-__device__ __forceinline__ void shade_bwd(const Geom &g, const MapK &m, const Dots &d, const Lobe lb[NL],
+__device__ __forceinline__ void shade_bwd(const VConst &K, const Geom &g, const MapK &m, const Dots &d, const Lobe lb[NL],
                                           const float F[3], const float f[3], const float g_rad[3], Grad &acc)
 {
     float g_LNp = 0.0f, sSp = 0.0f, W[NL];
-    constexpr float inv_pi = 1.0f / kPi;
+    const float inv_pi = K.inv_pi;
 #pragma unroll
     for (int l = 0; l < NL; ++l) W[l] = 0.0f;
 #pragma unroll
@@ -289,9 +309,9 @@ __device__ __forceinline__ void shade_bwd(const Geom &g, const MapK &m, const Do
     float g_NH = (sN * 2.0f) * d.NH;
     float g_VN = -d.iVN * fma_(2.0f * sV, d.iVN * d.iVN, sSp);
     float g_LN = -d.iLN * fma_(2.0f * sL, d.iLN * d.iLN, sSp);
-    if (!(d.nh_raw >= kMinDot)) g_NH = 0.0f;
-    if (!(d.vn_raw >= kMinDot)) g_VN = 0.0f;
-    if (!(d.ln_raw >= kMinDot)) g_LN = 0.0f;
+    if (!(d.nh_raw >= K.tiny)) g_NH = 0.0f;
+    if (!(d.vn_raw >= K.tiny)) g_VN = 0.0f;
+    if (!(d.ln_raw >= K.tiny)) g_LN = 0.0f;
     if (!(d.ln_raw >= 0.0f)) g_LNp = 0.0f;
     const float gl = g_LN + g_LNp;
     acc.n[0] = fma_(g_NH, g.hx, fma_(g_VN, g.wox, fma_(gl, g.wix, acc.n[0])));
@@ -405,17 +425,18 @@ __device__ __forceinline__ void render_fwd_loop(const MapK mk[VEC], const float 
                                                 const float *__restrict__ scp, float *__restrict__ o,
                                                 size_t plane, int S)
 {
+    const VConst K = make_vconst();
     for (int s = 0; s < S; ++s, scp += 9, o += 3 * plane) {
         float sc[9];
         load_scene(scp, sc);
         float rad[VEC][3];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            const Geom g = geometry(sc, x[v], y);
-            const Dots d = dots(g, mk[v]);
+            const Geom g = geometry(K, sc, x[v], y);
+            const Dots d = dots(K, g, mk[v]);
             Lobe lb[NL];
             float F[3], f[3];
-            shade<NL, false>(g, mk[v], d, lb, F, f, rad[v]);
+            shade<NL, false>(K, g, mk[v], d, lb, F, f, rad[v]);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -465,6 +486,7 @@ __device__ __forceinline__ void render_bwd_loop(const MapK mk[VEC], const float 
                                                 const float *__restrict__ scp, const float *__restrict__ go,
                                                 size_t plane, int S, Grad acc[VEC])
 {
+    const VConst K = make_vconst();
     for (int s = 0; s < S; ++s, scp += 9, go += 3 * plane) {
         float sc[9];
         load_scene(scp, sc);
@@ -473,13 +495,13 @@ __device__ __forceinline__ void render_bwd_loop(const MapK mk[VEC], const float 
         for (int k = 0; k < 3; ++k) load_vec<VEC>(go + (size_t)k * plane, gr[k]);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            const Geom g = geometry(sc, x[v], y);
-            const Dots d = dots(g, mk[v]);
+            const Geom g = geometry(K, sc, x[v], y);
+            const Dots d = dots(K, g, mk[v]);
             Lobe lb[NL];
             float F[3], f[3], rad[3];
-            shade<NL, true>(g, mk[v], d, lb, F, f, rad);
+            shade<NL, true>(K, g, mk[v], d, lb, F, f, rad);
             const float g_rad[3] = {gr[0][v], gr[1][v], gr[2][v]};
-            shade_bwd<NL>(g, mk[v], d, lb, F, f, g_rad, acc[v]);
+            shade_bwd<NL>(K, g, mk[v], d, lb, F, f, g_rad, acc[v]);
         }
     }
 }
@@ -546,33 +568,33 @@ constexpr unsigned long long kLossSumMask = (1ULL << kLossCountShift) - 1;
 
 // one (pixel, scene) of the fused loss: both shadings, log/L1, adjoint of the input shading
 template <int NL, bool WITH_GRAD>
-__device__ __forceinline__ void loss_pixel_scene(const float sc[9], float x, float y, const MapK &mi, const MapK &mt,
-                                                 float eps, float inv_count, float &lsum, Grad &acc)
+__device__ __forceinline__ void loss_pixel_scene(const VConst &K, const float sc[9], float x, float y, const MapK &mi,
+                                                 const MapK &mt, float eps, float inv_count, float &lsum, Grad &acc)
 {
-    constexpr float kLn2 = 0.693147180559945309417f;
-    const Geom g = geometry(sc, x, y);
+    const Geom g = geometry(K, sc, x, y);
     float rt[3];
     {
-        const Dots dt = dots(g, mt);
+        const Dots dt = dots(K, g, mt);
         Lobe lt[NL];
         float Ft[3], ft[3];
-        shade<NL, false>(g, mt, dt, lt, Ft, ft, rt);
+        shade<NL, false>(K, g, mt, dt, lt, Ft, ft, rt);
     }
-    const Dots di = dots(g, mi);
+    const Dots di = dots(K, g, mi);
     Lobe li[NL];
     float Fi[3], fi[3], ri[3], g_rad[3];
-    shade<NL, WITH_GRAD>(g, mi, di, li, Fi, fi, ri);
+    shade<NL, WITH_GRAD>(K, g, mi, di, li, Fi, fi, ri);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        // losses.py:46-50: |log(ri + eps) - log(rt + eps)|, v_log_f32 = log2
+        // losses.py:46-50: |log(ri + eps) - log(rt + eps)|, v_log_f32 = log2.  (Merging the two
+        // logs into log2(at * rcp(ai)) was measured: no gain, and it perturbs near-zero deltas.)
         const float ai = ri[k] + eps, at = rt[k] + eps;
-        const float delta = kLn2 * (__builtin_amdgcn_logf(ai) - __builtin_amdgcn_logf(at));
+        const float delta = K.ln2 * (__builtin_amdgcn_logf(ai) - __builtin_amdgcn_logf(at));
         lsum += fabsf(delta);
         // d|delta|/d ri = sign(delta)/(N*ai), sign(0) = 0 as in torch
-        const float sg = __builtin_amdgcn_fmed3f(delta * 1.0e30f, -1.0f, 1.0f);
+        const float sg = __builtin_amdgcn_fmed3f(delta * K.huge, -1.0f, 1.0f);
         g_rad[k] = sg * (inv_count * rcp_(ai));
     }
-    if (WITH_GRAD) shade_bwd<NL>(g, mi, di, li, Fi, fi, g_rad, acc);
+    if (WITH_GRAD) shade_bwd<NL>(K, g, mi, di, li, Fi, fi, g_rad, acc);
 }
 
 // Scene loop of K3, unrolled by two with the scene scalars double-buffered: the loads of
@@ -584,6 +606,9 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt,
                                                  Grad &acc)
 {
     float lsum = 0.0f;
+    const VConst K = make_vconst();
+    eps = vreg(eps);
+    inv_count = vreg(inv_count);
     float scA[9], scB[9];
     load_scene(scp, scA);
     for (int s = 0;; s += 2, scp += 18) {
@@ -593,13 +618,13 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt,
         const bool moreB = s + 1 < S;
         load_scene(scp + (moreB ? 9 : 0), scB);
         __builtin_amdgcn_sched_barrier(0);
-        loss_pixel_scene<NL, WITH_GRAD>(scA, x, y, mi, mt, eps, inv_count, lsum, acc);
+        loss_pixel_scene<NL, WITH_GRAD>(K, scA, x, y, mi, mt, eps, inv_count, lsum, acc);
         if (!moreB) break;
         asm volatile("" ::"s"(scB[0]), "s"(scB[8]));
         const bool moreA = s + 2 < S;
         load_scene(scp + (moreA ? 18 : 9), scA);
         __builtin_amdgcn_sched_barrier(0);
-        loss_pixel_scene<NL, WITH_GRAD>(scB, x, y, mi, mt, eps, inv_count, lsum, acc);
+        loss_pixel_scene<NL, WITH_GRAD>(K, scB, x, y, mi, mt, eps, inv_count, lsum, acc);
         if (!moreA) break;
     }
     return lsum;
@@ -620,7 +645,7 @@ __device__ __forceinline__ float signed_scale(float delta, float scale)
 // One thread = one pixel (VEC = 1: the kernel is VALU-bound, wider loads measured no gain
 // and cost occupancy).  WITH_L1 adds SVBRDFL1Loss on the 24 values already in registers.
 template <bool WITH_GRAD, bool WITH_L1>
-__global__ __launch_bounds__(kLossThreads) void k_rendering_loss(const float *__restrict__ input,
+__global__ __launch_bounds__(kLossThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_rendering_loss(const float *__restrict__ input,
                                                                  const float *__restrict__ target,
                                                                  const float *__restrict__ scenes,
                                                                  const float *__restrict__ xrow, float eps,
