@@ -14,8 +14,9 @@ not an importable Python identifier.)
 There is no CPU implementation in this package: every compute entry point raises if
 the HIP extension is missing or the tensors are not on a ROCm device.
 """
-from . import distributed, environment, losses, renderers, utils  # noqa: F401
+from . import distributed, environment, losses, renderers, synthesis, utils  # noqa: F401
 from ._native import NativeLibraryError, library_path  # noqa: F401
 
-__all__ = ["environment", "losses", "renderers", "utils", "NativeLibraryError", "library_path"]
+__all__ = ["environment", "losses", "renderers", "synthesis", "utils", "distributed", "NativeLibraryError",
+           "library_path"]
 __version__ = "0.1.0"

@@ -117,7 +117,7 @@ def xrow(device, W):
 
 def _workspace(device, nbytes):
     # one scratch buffer per (device, stream): calls on different streams never share it
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _raw_stream(device))
     t = _workspace_cache.get(key)
     if t is None or t.numel() * 8 < nbytes:
         # zero-initialised once; every completed kernel leaves it zeroed (see svbrdf_hip.h)
@@ -126,8 +126,29 @@ def _workspace(device, nbytes):
     return t
 
 
+def _raw_stream(device):
+    return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+
+
 def _stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(_raw_stream(device))
+
+
+class _on_device:
+    """`with torch.cuda.device(d)` only when d is not already current (the common case costs ~nothing)"""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, device):
+        self.ctx = None if device.index == torch.cuda.current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 def _dims(maps, scenes):
@@ -148,7 +169,7 @@ def render_fwd(maps, scenes):
     maps, scenes = maps.contiguous(), scenes.contiguous()
     B, S, H, W = _dims(maps, scenes)
     out = torch.empty((B, S, 3, H, W), dtype=torch.float32, device=maps.device)
-    with torch.cuda.device(maps.device):
+    with _on_device(maps.device):
         _check(_load().svbrdf_render_fwd(maps.data_ptr(), scenes.data_ptr(), xrow(maps.device, W).data_ptr(),
                                          out.data_ptr(), B, S, H, W, _stream(maps.device)), "svbrdf_render_fwd")
     return out
@@ -164,7 +185,7 @@ def render_bwd(maps, scenes, grad_out):
     if tuple(grad_out.shape) != (B, S, 3, H, W):
         raise ValueError("grad_out must be [B,S,3,H,W]")
     grad = torch.empty_like(maps)
-    with torch.cuda.device(maps.device):
+    with _on_device(maps.device):
         _check(_load().svbrdf_render_bwd(maps.data_ptr(), scenes.data_ptr(), xrow(maps.device, W).data_ptr(),
                                          grad_out.data_ptr(), grad.data_ptr(), B, S, H, W, _stream(maps.device)),
                "svbrdf_render_bwd")
@@ -190,7 +211,7 @@ def rendering_loss(input, target, scenes, eps=0.1, want_grad=True, l1_weight=0.0
     grad = torch.empty_like(input) if want_grad else None
     xr = xrow(input.device, W)
     hook = _launch_hook
-    with torch.cuda.device(input.device):
+    with _on_device(input.device):
         if hook is not None:
             hook("begin")
         if l1_weight != 0.0:
@@ -216,7 +237,7 @@ def scale_inplace_(data, scale):
     _require_device_f32(scale, "scale")
     if not data.is_contiguous() or scale.numel() != 1:
         raise ValueError("scale_inplace_ needs a contiguous tensor and a one-element scale")
-    with torch.cuda.device(data.device):
+    with _on_device(data.device):
         _check(_load().svbrdf_scale_inplace(data.data_ptr(), scale.data_ptr(), data.numel(), _stream(data.device)),
                "svbrdf_scale_inplace")
     return data

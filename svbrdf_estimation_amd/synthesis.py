@@ -1,0 +1,83 @@
+"""On-GPU synthesis of the network's input photographs.
+
+The reference renders missing input photos inside its CPU dataloader, one 256x256 image at a
+time with the eager ``LocalRenderer`` (development/multiImage_pytorch/dataset.py:94-98 ->
+``render_inputs`` :162-221): fronto-parallel first view, cosine-hemisphere views after it,
+optional light-power / white-balance / view-distance augmentation, Gaussian sensor noise,
+clamp to [0,1].  Here the scenes are drawn on the host with the reference's RNG call sequence
+and all ``count`` photos of all batch items are rendered by ONE launch of the forward kernel
+K1, reading each SVBRDF once.
+
+Noise: the reference draws the per-pixel noise from the CPU generator.  ``noise="cpu"`` does the
+same (bit-identical noise field, costs a 3*H*W draw + upload per image); ``noise="device"``
+(default) draws it with the device generator (fast, statistically identical, different
+numbers); ``noise=None`` disables it.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _native, utils
+
+MIN_EPS, MAX_EPS = 0.001, 0.02           # dataset.py:164-165
+FIXED_LIGHT_DISTANCE = 2.197             # dataset.py:166
+FIXED_VIEW_DISTANCE = 2.75               # dataset.py:167
+
+
+def input_scene_table(count, use_augmentation=True):
+    """[count,9] scenes of ONE sample, RNG call order of dataset.py:172-204."""
+    light = torch.cat((torch.empty(2).uniform_(-0.75, 0.75), torch.ones(1) * FIXED_LIGHT_DISTANCE)).unsqueeze(0)
+    if count > 1:
+        hemi = utils.generate_normalized_random_direction(count - 1, min_eps=MIN_EPS, max_eps=MAX_EPS)
+        light = torch.cat((light, hemi * FIXED_LIGHT_DISTANCE), dim=0)
+    colors = torch.tensor([30.0]).unsqueeze(-1)
+    if use_augmentation:
+        std = torch.exp(torch.empty(1).normal_(mean=-2.0, std=0.5)).numpy()[0]
+        colors = torch.abs(torch.empty(count).normal_(mean=20.0, std=std)).unsqueeze(-1)
+    colors = colors.expand(count, 3)
+    if use_augmentation:
+        colors = colors * torch.abs(torch.empty(count, 3).normal_(mean=1.0, std=0.03))   # white balance
+        view_distance = torch.empty(count).uniform_(0.25, 2.75)
+    else:
+        view_distance = torch.ones(count) * FIXED_VIEW_DISTANCE
+    view = torch.cat((torch.empty(2).uniform_(-0.25, 0.25), view_distance[:1])).unsqueeze(0)
+    if count > 1:
+        hemi = utils.generate_normalized_random_direction(count - 1, min_eps=MIN_EPS, max_eps=MAX_EPS)
+        view = torch.cat((view, hemi * view_distance[1:].unsqueeze(-1)), dim=0)
+    return torch.cat((view, light, colors), dim=-1).contiguous()
+
+
+def noise_std():
+    """per-image noise level, dataset.py:215"""
+    return torch.exp(torch.empty(1).normal_(mean=np.log(0.005), std=0.3)).numpy()[0]
+
+
+def render_inputs(svbrdf, count, use_augmentation=True, noise="device"):
+    """svbrdf [12,H,W] (one sample, like the reference) or [B,12,H,W] on a ROCm device ->
+    [count,3,H,W] / [B,count,3,H,W] linear-RGB input photos in [0,1]."""
+    single = svbrdf.dim() == 3
+    maps = svbrdf.unsqueeze(0) if single else svbrdf
+    if maps.dim() != 4 or maps.shape[1] != 12:
+        raise ValueError("svbrdf must be [12,H,W] or [B,12,H,W]")
+    B, _, H, W = maps.shape
+    if noise not in (None, "cpu", "device"):
+        raise ValueError("noise must be None, 'cpu' or 'device'")
+    tables, fields = [], []
+    for _ in range(B):
+        tables.append(input_scene_table(count, use_augmentation))
+        if noise == "cpu":      # reference order: after a sample's scenes, per image: level, then the field
+            per_image = []
+            for _i in range(count):
+                std = noise_std()
+                per_image.append(torch.zeros(1, 3, H, W).normal_(mean=0.0, std=std))
+            fields.append(torch.cat(per_image, dim=0))
+    table = torch.stack(tables, dim=0).to(maps.device, non_blocking=True)
+    out = _native.render_fwd(maps.detach(), table)                      # K1: [B,count,3,H,W]
+    if noise == "cpu":
+        out = out + torch.stack(fields, dim=0).to(maps.device, non_blocking=True)
+    elif noise == "device":
+        stds = torch.tensor([[float(noise_std()) for _i in range(count)] for _b in range(B)], device=maps.device)
+        out = out + torch.randn_like(out) * stds.view(B, count, 1, 1, 1)
+    out = out.clamp_(0.0, 1.0)
+    return out[0] if single else out

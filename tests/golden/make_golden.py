@@ -265,6 +265,40 @@ def g8_utils():
          magic_pixel=np.float64(1.3703509847201), magic_decoded=np.float64(2.0))
 
 
+def g10_render_inputs():
+    """dataset.py:162-221 render_inputs: scenes (captured at the renderer call) and final photos"""
+    import dataset as ref_dataset
+
+    class FakeSelf:          # render_inputs only reads self.use_augmentation
+        pass
+    captured = []
+    orig = ref_renderers.LocalRenderer.render
+
+    def spy(self_r, scene, svbrdf):
+        captured.append(scene_row(scene))
+        return orig(self_r, scene, svbrdf)
+    arrays = {}
+    ref_renderers.LocalRenderer.render = spy
+    try:
+        for aug in (False, True):
+            for count in (1, 4):
+                maps = synth.make_maps(500 + count, 1, 32)[0]
+                fs = FakeSelf()
+                fs.use_augmentation = aug
+                del captured[:]
+                torch.manual_seed(40 + count + (100 if aug else 0))
+                out = ref_dataset.SvbrdfDataset.render_inputs(fs, torch.from_numpy(maps), count)
+                key = "aug%d_n%d" % (int(aug), count)
+                arrays[key + "__maps"] = maps
+                arrays[key + "__scenes"] = np.stack(captured)
+                arrays[key + "__out"] = out.numpy()
+                arrays[key + "__seed"] = np.int64(40 + count + (100 if aug else 0))
+                arrays[key + "__rng_after"] = torch.get_rng_state().numpy()[:64].copy()
+    finally:
+        ref_renderers.LocalRenderer.render = orig
+    save("g10_render_inputs.npz", **arrays)
+
+
 def g9_kat():
     R = ref_renderers.LocalRenderer()
     out = {}
@@ -296,6 +330,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--only-untied-loss":   # added after the first freeze
         g3_loss("g3_loss_20_untied.npz", 2, 20, 141, 13, tiled=False)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-render-inputs":  # row f3, added later
+        g10_render_inputs()
+        return
     g1_render_64()
     g2_lattice(256, 8, 111)
     g2_lattice(512, 16, 112)
@@ -307,6 +344,7 @@ def main():
     g6_linspace()
     g8_utils()
     g9_kat()
+    g10_render_inputs()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "mworchel/svbrdf-estimation @ /root/reference (development/multiImage_pytorch)",

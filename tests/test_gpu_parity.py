@@ -406,3 +406,36 @@ def test_optimisation_through_the_loss_decreases(dev):
         first = loss.item() if first is None else first
         last = loss.item()
     assert last < 0.6 * first
+
+
+# ---------------------------------------------------------------- row f3: input-photo synthesis on the GPU
+
+def test_render_inputs_matches_reference_dataloader(dev, oracle, golden):
+    """dataset.py:162-221 on the GPU: same scenes, same (CPU-drawn) noise field, same photos, and the
+    CPU generator ends in the same state as after the reference's call"""
+    from svbrdf_estimation_amd import synthesis
+    g = golden("g10_render_inputs.npz")
+    for aug in (0, 1):
+        for n in (1, 4):
+            k = "aug%d_n%d" % (aug, n)
+            torch.manual_seed(int(g[k + "__seed"]))
+            out = synthesis.render_inputs(_t(g[k + "__maps"], dev), n, use_augmentation=bool(aug), noise="cpu")
+            assert tuple(out.shape) == (n, 3, 32, 32)
+            assert np.array_equal(torch.get_rng_state().numpy()[:64], g[k + "__rng_after"]), k
+            ref = g[k + "__out"]
+            err = np.abs(_np(out) - ref)
+            # photos are clamped to [0,1]; a highlight pixel carries the reference's own sqrt noise
+            # (DESIGN.md 4.2), so: 99.9 % within 1e-5 rel + 2e-6, every pixel within 3e-5 absolute
+            assert (err <= 1e-5 * np.abs(ref) + 2e-6).mean() >= 0.999, (k, err.max())
+            assert err.max() <= 3e-5, (k, err.max())
+            assert out.min().item() >= 0.0 and out.max().item() <= 1.0
+    # batched: B samples x count photos in one launch; device noise is statistically right
+    maps = _t(synth.make_maps(510, 3, 32), dev)
+    torch.manual_seed(1)
+    clean = synthesis.render_inputs(maps, 2, noise=None)
+    torch.manual_seed(1)
+    noisy = synthesis.render_inputs(maps, 2, noise="device")
+    assert tuple(noisy.shape) == (3, 2, 3, 32, 32)
+    inner = (clean > 0.05) & (clean < 0.95)
+    resid = (noisy - clean)[inner]
+    assert abs(resid.mean().item()) < 2e-3 and 1e-3 < resid.std().item() < 3e-2

@@ -116,6 +116,21 @@ def test_rendering_loss_sampling_order_matches_reference(golden):
     assert np.array_equal(fn.sample_scene_table(3).numpy(), g3["scenes"])
 
 
+def test_input_synthesis_scene_tables_bit_exact(golden):
+    """row f3: scene construction of dataset.py:172-204 (with and without augmentation)"""
+    from svbrdf_estimation_amd import synthesis
+    g = golden("g10_render_inputs.npz")
+    for aug in (0, 1):
+        for n in (1, 4):
+            k = "aug%d_n%d" % (aug, n)
+            torch.manual_seed(int(g[k + "__seed"]))
+            assert np.array_equal(synthesis.input_scene_table(n, bool(aug)).numpy(), g[k + "__scenes"]), k
+    with pytest.raises(ValueError):
+        synthesis.render_inputs(torch.zeros(9, 4, 4), 1)
+    with pytest.raises(Exception):
+        synthesis.render_inputs(torch.zeros(12, 4, 4), 1)      # CPU tensor: no fallback
+
+
 # ------------------------------------------------------------------ utils.py
 
 def test_utils_against_reference(golden):
