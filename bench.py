@@ -150,9 +150,19 @@ def main():
         i = state["i"]
         if 0 <= i < len(ev):
             ev[i][0 if phase == "begin" else 1].record(torch.cuda.current_stream(dev))
-    _native.set_launch_hook(hook)
+    _native.set_launch_hook(hook)             # ctypes host path
+    from svbrdf_estimation_amd import _hostext
+    ext = _hostext.module()                   # native host path: the pair is recorded inside the extension
+    if ext is not None:
+        for a, b in ev:                       # create the raw hipEvent handles
+            a.record()
+            b.record()
+        torch.cuda.synchronize(dev)
 
     def step():
+        i = state["i"]
+        if ext is not None and 0 <= i < len(ev):
+            ext.set_timing_events(ev[i][0].cuda_event, ev[i][1].cuda_event)
         inp.grad = None
         loss = loss_fn(inp, tgt)
         loss.backward()
@@ -220,6 +230,7 @@ def main():
                          "valu_frac_of_fp32_peak": (FLOP_PER_PIXEL_SCENE * H * H * S * B / (kernel_ms_avg * 1e-3))
                                                    / (FP32_VALU_PEAK_TFLOPS * 1e12)},
             "loss": mean_loss,
+            "host_path": "native C++ extension (csrc/host_ext.cpp)" if ext is not None else "python + ctypes",
         }
         if world == 1 and not args.no_cpu_baseline:
             table = loss_fn.sample_scene_table(B)

@@ -1,0 +1,60 @@
+"""Loader of the optional native host path (csrc/host_ext.cpp).
+
+The extension moves the per-call host work of the fused loss -- scene sampling, table upload,
+kernel launch, autograd node -- out of the Python interpreter; it launches exactly the same
+HIP kernels through the same C ABI as the ctypes binding, so results are identical.  It is
+built in-tree by ``__graft_entry__.build()``; when it is absent (or ``SVBRDF_NO_HOST_EXT=1``)
+the ctypes path in ``_native.py`` is used.  Neither path computes anything on the CPU.
+"""
+import importlib.machinery
+import importlib.util
+import os
+
+import torch  # noqa: F401  (the extension links against libtorch)
+
+from . import _native
+
+NAME = "svbrdf_host_ext"
+BUILD_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "host_ext")
+_SO = os.path.join(BUILD_DIR, NAME + ".so")
+_mod = None
+_tried = False
+
+
+def build(verbose=False):
+    """compile csrc/host_ext.cpp with torch.utils.cpp_extension into lib/host_ext/ (in-tree)"""
+    from torch.utils import cpp_extension
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "host_ext.cpp")
+    cpp_extension.load(name=NAME, sources=[src], build_directory=BUILD_DIR, extra_cflags=["-O2", "-std=c++17"],
+                       extra_ldflags=["-ldl"], verbose=verbose)
+    return _SO
+
+
+_disabled = False
+
+
+def set_enabled(flag):
+    """switch between the native host path and the ctypes path at run time (tests compare the two)"""
+    global _disabled
+    _disabled = not flag
+
+
+def module():
+    """the bound extension module, or None if it is not built / disabled"""
+    global _mod, _tried
+    if _disabled:
+        return None
+    if _mod is not None or _tried:
+        return _mod
+    _tried = True
+    if os.environ.get("SVBRDF_NO_HOST_EXT") or not os.path.exists(_SO):
+        return None
+    loader = importlib.machinery.ExtensionFileLoader(NAME, _SO)
+    spec = importlib.util.spec_from_loader(NAME, loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    _native._load()                       # make sure libsvbrdf_hip.so (and torch's HIP runtime) are in the process
+    mod.bind(_native.library_path())
+    _mod = mod
+    return _mod

@@ -12,7 +12,7 @@ tracer) goes through the generic per-scene loop built from that renderer's own o
 import torch
 import torch.nn as nn
 
-from . import _native, environment, renderers, utils
+from . import _hostext, _native, environment, renderers, utils
 
 
 class SVBRDFL1Loss(nn.Module):
@@ -94,12 +94,19 @@ class RenderingLoss(nn.Module):
 
     def _forward_fused(self, input, target, l1_weight=0.0, eps_l1=0.01):
         _check_shapes(input, target)
+        ext = _hostext.module() if input.is_cuda else None
+        if ext is not None and input.dtype == torch.float32 and target.dtype == torch.float32 \
+                and input.device.index == torch.cuda.current_device():
+            # native host path: same draws, same kernels, no interpreter in the loop
+            return ext.fused_loss(input, target, int(self.random_configuration_count),
+                                  int(self.specular_configuration_count), float(self.epsilon_render),
+                                  float(l1_weight), float(eps_l1), _native._raw_stream(input.device))
         table = self.sample_scene_table(input.shape[0])
         if not input.is_cuda:
             raise _native.NativeLibraryError(
                 "RenderingLoss with the MI355X LocalRenderer needs tensors on a ROCm device "
                 "(got %s); there is no CPU fallback" % input.device)
-        return _FusedRenderingLoss.apply(input, target, table.to(input.device, non_blocking=True),
+        return _FusedRenderingLoss.apply(input, target, _native.upload_scene_table(table, input.device),
                                          self.epsilon_render, float(l1_weight), float(eps_l1))
 
     def _forward_plugin(self, input, target):

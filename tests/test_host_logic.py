@@ -103,6 +103,21 @@ def test_batch_sampler_equals_per_item_draws_and_rng_state(B, R, M):
         assert torch.equal(a, b) and torch.equal(sa, torch.get_rng_state()), (B, R, M, seed)
 
 
+def test_cpp_sampler_equals_per_item_draws_and_rng_state():
+    """the native host path's sampler (csrc/host_ext.cpp) against the per-item reference order"""
+    from svbrdf_estimation_amd import _hostext, environment as env
+    ext = _hostext.module()
+    assert ext is not None, "host extension not built"
+    for (B, R, M) in [(8, 3, 6), (2, 11, 21), (5, 0, 4), (3, 2, 0), (3, 1, 7), (3, 1, 8)]:
+        for seed in range(10):
+            torch.manual_seed(seed)
+            a = torch.stack([env.scene_table(R, M) for _ in range(B)])
+            sa = torch.get_rng_state()
+            torch.manual_seed(seed)
+            b = ext.sample_scene_table(B, R, M)
+            assert torch.equal(a, b) and torch.equal(sa, torch.get_rng_state()), (B, R, M, seed)
+
+
 def test_rendering_loss_sampling_order_matches_reference(golden):
     from svbrdf_estimation_amd import losses, renderers
     g = golden("g5_scene_sampler.npz")

@@ -40,3 +40,39 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(300): step()
 pr.disable(); torch.cuda.synchronize()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(18); print(s.getvalue()[:3500])
+
+# ---- finer split of the autograd cost
+import time
+def split():
+    fw = bw = 0.0
+    for _ in range(300):
+        inp.grad = None
+        t0 = time.perf_counter()
+        l = losses._FusedRenderingLoss.apply(inp, tgt, td, 0.1)
+        t1 = time.perf_counter()
+        l.backward()
+        t2 = time.perf_counter()
+        fw += t1 - t0; bw += t2 - t1
+    print("Function.apply (forward): %.1f us   loss.backward(): %.1f us" % (fw / 300 * 1e6, bw / 300 * 1e6))
+split()
+x = torch.ones(1, device=dev, requires_grad=True)
+def tiny():
+    y = (x * 2.0).sum(); y.backward()
+print("tiny builtin-op graph fwd+bwd: host %.1f us" % T(tiny)[0])
+class Id(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a): return a.view(())
+    @staticmethod
+    def backward(ctx, g): return g.reshape(1)
+def tiny_fn():
+    y = Id.apply(x); y.backward()
+print("trivial python Function fwd+bwd: host %.1f us" % T(tiny_fn)[0])
+
+# ---- native host path (C++ extension)
+from svbrdf_estimation_amd import _hostext
+ext = _hostext.module()
+print("host extension:", ext)
+if ext is not None:
+    print("C++ sampler: %.1f us" % T(lambda: ext.sample_scene_table(8, 3, 6))[0])
+    print("step via RenderingLoss (ext path): host %.1f us wall %.1f" % T(step))
+    os.environ["X"] = "1"
