@@ -105,6 +105,19 @@ SVBRDF_API int svbrdf_mixed_loss_fwd_bwd(const float *input, const float *target
                                          float *loss_out, float *grad_input, void *workspace,
                                          size_t workspace_bytes, int B, int S, int H, int W, void *stream);
 
+/* K3 with the network head folded in (the north star's "normal-map
+ * decode"): `encoded9` is the generator's [B,9,H,W] output AFTER tanh, channels
+ * normals_xy(0:2) | diffuse(2:5) | roughness(5) | specular(6:9) (utils.py:49-53).  The kernel
+ * decodes it exactly like models.py:338-346 (utils.decode_svbrdf, then (x+1)/2 for
+ * diffuse/roughness/specular), evaluates the mixed loss against the 12-channel `target`
+ * (l1_weight = 0: rendering loss only) and returns d loss / d encoded9 in `grad_encoded9`
+ * ([B,9,H,W], or NULL).  Replaces ~15 elementwise launches of the model head and their
+ * backward; HBM traffic 120 instead of 144 bytes per pixel. */
+SVBRDF_API int svbrdf_head_loss_fwd_bwd(const float *encoded9, const float *target, const float *scenes,
+                                        const float *xrow, float eps_render, float l1_weight, float eps_l1,
+                                        float *loss_out, float *grad_encoded9, void *workspace,
+                                        size_t workspace_bytes, int B, int S, int H, int W, void *stream);
+
 /* data[i] *= scale_dev[0] for i < n, on the device and without a host sync; when the
  * scalar is exactly 1.0 the kernel exits without touching `data`.  Used by the autograd
  * wrapper to apply the upstream gradient of the loss (the chain rule through

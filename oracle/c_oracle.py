@@ -127,3 +127,31 @@ def mixed_loss(input, target, scenes, l1_weight=0.1, eps=0.1, eps_l1=0.01, xrow=
     if rc:
         raise RuntimeError("oracle mixed_loss rc=%d" % rc)
     return loss.value, grad
+
+
+def head_decode(encoded9):
+    """models.py:338-346: [B,9,H,W] post-tanh generator output -> [B,12,H,W] maps."""
+    enc = _f32(encoded9)
+    assert enc.ndim == 4 and enc.shape[1] == 9
+    B, _, H, W = enc.shape
+    maps = np.empty((B, 12, H, W), dtype=np.float32)
+    rc = lib().svbrdf_oracle_head_decode(_p(enc), _p(maps), B, H, W)
+    if rc:
+        raise RuntimeError("oracle head_decode rc=%d" % rc)
+    return maps
+
+
+def head_loss(encoded9, target, scenes, l1_weight=0.1, eps=0.1, eps_l1=0.01, xrow=None, want_grad=True, f64=False):
+    """mixed loss of the decoded head output; gradient w.r.t. the 9 encoded channels (float64 array)."""
+    enc = _f32(encoded9)
+    target, scenes, B, S, H, W = _dims(target, scenes)
+    assert enc.shape == (B, 9, H, W)
+    xrow = make_xrow(W) if xrow is None else _f32(xrow)
+    loss = ctypes.c_double(0.0)
+    grad = np.empty((B, 9, H, W), dtype=np.float64) if want_grad else None
+    rc = lib().svbrdf_oracle_head_loss(_p(enc), _p(target), _p(scenes), _p(xrow), ctypes.c_float(eps),
+                                       ctypes.c_float(l1_weight), ctypes.c_float(eps_l1), ctypes.byref(loss),
+                                       _p(grad, _f64p) if want_grad else None, int(bool(f64)), B, S, H, W)
+    if rc:
+        raise RuntimeError("oracle head_loss rc=%d" % rc)
+    return loss.value, grad

@@ -72,6 +72,8 @@ def _load():
             [_fp, _fp, _fp, _fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, ctypes.c_size_t]
             + [ctypes.c_int] * 4 + [_fp])
         lib.svbrdf_mixed_loss_fwd_bwd.restype = ctypes.c_int
+        lib.svbrdf_head_loss_fwd_bwd.argtypes = lib.svbrdf_mixed_loss_fwd_bwd.argtypes
+        lib.svbrdf_head_loss_fwd_bwd.restype = ctypes.c_int
         lib.svbrdf_scale_inplace.argtypes = [_fp, _fp, ctypes.c_size_t, _fp]
         lib.svbrdf_scale_inplace.restype = ctypes.c_int
         for name in ("svbrdf_make_xrow", "svbrdf_render_fwd", "svbrdf_render_bwd", "svbrdf_rendering_loss_fwd_bwd"):
@@ -192,18 +194,23 @@ def render_bwd(maps, scenes, grad_out):
     return grad
 
 
-def rendering_loss(input, target, scenes, eps=0.1, want_grad=True, l1_weight=0.0, eps_l1=0.01):
+def rendering_loss(input, target, scenes, eps=0.1, want_grad=True, l1_weight=0.0, eps_l1=0.01, head=False):
     """K3: fused rendering loss (+ d loss/d input); with l1_weight != 0 the SVBRDF L1 loss is folded
-    in (MixedLoss).  Returns (loss [1] device tensor, grad or None)."""
+    in (MixedLoss); with head=True `input` is the generator's [B,9,H,W] post-tanh output and the
+    network head is decoded in the kernel.  Returns (loss [1] device tensor, grad or None)."""
     _require_device_f32(input, "input")
     _require_device_f32(target, "target")
     _require_device_f32(scenes, "scenes")
-    if input.shape != target.shape:
+    if head:
+        if input.dim() != 4 or input.shape[1] != 9 or (input.shape[0],) + tuple(input.shape[2:]) != \
+                (target.shape[0],) + tuple(target.shape[2:]):
+            raise ValueError("head=True needs input [B,9,H,W] and target [B,12,H,W]")
+    elif input.shape != target.shape:
         raise ValueError("input and target shapes differ: %s vs %s" % (tuple(input.shape), tuple(target.shape)))
     if target.device != input.device or scenes.device != input.device:
         raise ValueError("input, target and scenes must be on the same device")
     input, target, scenes = input.contiguous(), target.contiguous(), scenes.contiguous()
-    B, S, H, W = _dims(input, scenes)
+    B, S, H, W = _dims(target, scenes)
     lib = _load()
     nbytes = lib.svbrdf_rendering_loss_workspace_bytes(B, S, H, W)
     ws = _workspace(input.device, nbytes)
@@ -214,7 +221,13 @@ def rendering_loss(input, target, scenes, eps=0.1, want_grad=True, l1_weight=0.0
     with _on_device(input.device):
         if hook is not None:
             hook("begin")
-        if l1_weight != 0.0:
+        if head:
+            rc = lib.svbrdf_head_loss_fwd_bwd(
+                input.data_ptr(), target.data_ptr(), scenes.data_ptr(), xr.data_ptr(),
+                ctypes.c_float(eps), ctypes.c_float(l1_weight), ctypes.c_float(eps_l1), loss.data_ptr(),
+                grad.data_ptr() if want_grad else None, ws.data_ptr(), ws.numel() * 8, B, S, H, W,
+                _stream(input.device))
+        elif l1_weight != 0.0:
             rc = lib.svbrdf_mixed_loss_fwd_bwd(
                 input.data_ptr(), target.data_ptr(), scenes.data_ptr(), xr.data_ptr(),
                 ctypes.c_float(eps), ctypes.c_float(l1_weight), ctypes.c_float(eps_l1), loss.data_ptr(),
@@ -227,7 +240,8 @@ def rendering_loss(input, target, scenes, eps=0.1, want_grad=True, l1_weight=0.0
                 ws.data_ptr(), ws.numel() * 8, B, S, H, W, _stream(input.device))
         if hook is not None:
             hook("end")
-    _check(rc, "svbrdf_mixed_loss_fwd_bwd" if l1_weight != 0.0 else "svbrdf_rendering_loss_fwd_bwd")
+    _check(rc, "svbrdf_head_loss_fwd_bwd" if head else
+           ("svbrdf_mixed_loss_fwd_bwd" if l1_weight != 0.0 else "svbrdf_rendering_loss_fwd_bwd"))
     return loss, grad
 
 

@@ -35,6 +35,7 @@ using ev_sync_t = int (*)(void *);
 
 struct Abi {
     loss_fn_t mixed = nullptr;
+    loss_fn_t head = nullptr;     // same signature, input = [B,9,H,W] encoded head output
     scale_fn_t scale = nullptr;
     ws_fn_t ws_bytes = nullptr;
     err_fn_t last_error = nullptr;
@@ -54,6 +55,7 @@ void bind(const std::string &path)
         return p;
     };
     g_abi.mixed = reinterpret_cast<loss_fn_t>(need("svbrdf_mixed_loss_fwd_bwd"));
+    g_abi.head = reinterpret_cast<loss_fn_t>(need("svbrdf_head_loss_fwd_bwd"));
     g_abi.scale = reinterpret_cast<scale_fn_t>(need("svbrdf_scale_inplace"));
     g_abi.ws_bytes = reinterpret_cast<ws_fn_t>(need("svbrdf_rendering_loss_workspace_bytes"));
     g_abi.last_error = reinterpret_cast<err_fn_t>(need("svbrdf_last_error"));
@@ -180,9 +182,12 @@ struct State {
 // ------------------------------------------------------------------------------------------
 struct FusedLoss : public torch::autograd::Function<FusedLoss> {
     static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &input, const at::Tensor &target,
-                              const at::Tensor &scenes, double eps, double l1_weight, double eps_l1, int64_t stream)
+                              const at::Tensor &scenes, double eps, double l1_weight, double eps_l1, int64_t stream,
+                              bool head)
     {
         const bool need_in = input.requires_grad(), need_tg = target.requires_grad();
+        TORCH_CHECK(!(head && need_tg), "the head-fused loss has no gradient w.r.t. the target maps");
+        const loss_fn_t kernel = head ? g_abi.head : g_abi.mixed;
         const auto in = input.contiguous(), tg = target.contiguous();
         const int B = (int)in.size(0), S = (int)scenes.size(1), H = (int)in.size(2), W = (int)in.size(3);
         auto loss = at::empty({1}, in.options());
@@ -191,10 +196,10 @@ struct FusedLoss : public torch::autograd::Function<FusedLoss> {
         const size_t ws_bytes = (size_t)g_state.workspace.numel() * 8;
         if (need_in) grad_in = at::empty_like(in);
         if (g_state.ev_begin) g_abi.ev_record(g_state.ev_begin, st);
-        const int rc = g_abi.mixed(in.data_ptr<float>(), tg.data_ptr<float>(), scenes.data_ptr<float>(),
-                                   g_state.xrow.data_ptr<float>(), (float)eps, (float)l1_weight, (float)eps_l1,
-                                   loss.data_ptr<float>(), need_in ? grad_in.data_ptr<float>() : nullptr,
-                                   g_state.workspace.data_ptr(), ws_bytes, B, S, H, W, st);
+        const int rc = kernel(in.data_ptr<float>(), tg.data_ptr<float>(), scenes.data_ptr<float>(),
+                              g_state.xrow.data_ptr<float>(), (float)eps, (float)l1_weight, (float)eps_l1,
+                              loss.data_ptr<float>(), need_in ? grad_in.data_ptr<float>() : nullptr,
+                              g_state.workspace.data_ptr(), ws_bytes, B, S, H, W, st);
         if (g_state.ev_end) g_abi.ev_record(g_state.ev_end, st);
         g_state.ev_begin = g_state.ev_end = nullptr;
         check(rc, "svbrdf_mixed_loss_fwd_bwd");
@@ -234,7 +239,7 @@ struct FusedLoss : public torch::autograd::Function<FusedLoss> {
             gt = ctx->saved_data["grad_tg"].toTensor();
             check(g_abi.scale(gt.data_ptr<float>(), scale.data_ptr<float>(), (size_t)gt.numel(), st), "svbrdf_scale_inplace");
         }
-        return {gi, gt, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+        return {gi, gt, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     }
 };
 
@@ -257,11 +262,12 @@ void ensure_device_state(const at::Tensor &input, int S)
     }
 }
 
-void check_inputs(const at::Tensor &input, const at::Tensor &target)
+void check_inputs(const at::Tensor &input, const at::Tensor &target, bool head)
 {
     TORCH_CHECK(g_abi.mixed != nullptr, "host extension not bound to libsvbrdf_hip.so (call bind first)");
-    TORCH_CHECK(input.dim() == 4 && input.size(1) == 12 && input.sizes() == target.sizes(),
-                "input and target must both be [B,12,H,W]");
+    TORCH_CHECK(input.dim() == 4 && target.dim() == 4 && target.size(1) == 12 && input.size(1) == (head ? 9 : 12) &&
+                    input.size(0) == target.size(0) && input.size(2) == target.size(2) && input.size(3) == target.size(3),
+                head ? "input must be [B,9,H,W] and target [B,12,H,W]" : "input and target must both be [B,12,H,W]");
     TORCH_CHECK(input.is_cuda() && target.is_cuda() && input.device() == target.device(),
                 "the MI355X engine only computes on a ROCm device (no CPU fallback)");
     TORCH_CHECK(input.scalar_type() == at::kFloat && target.scalar_type() == at::kFloat, "fp32 only");
@@ -272,9 +278,9 @@ void check_inputs(const at::Tensor &input, const at::Tensor &target)
 
 // scenes drawn here, reference RNG order; returns the 0-dim loss on the device
 at::Tensor fused_loss(const at::Tensor &input, const at::Tensor &target, int64_t n_random, int64_t n_specular,
-                      double eps, double l1_weight, double eps_l1, int64_t stream)
+                      double eps, double l1_weight, double eps_l1, int64_t stream, bool head)
 {
-    check_inputs(input, target);
+    check_inputs(input, target, head);
     std::lock_guard<std::mutex> lock(g_state.mu);
     const int64_t B = input.size(0);
     if (g_state.sampler.B != B || g_state.sampler.R != n_random || g_state.sampler.M != n_specular)
@@ -282,20 +288,20 @@ at::Tensor fused_loss(const at::Tensor &input, const at::Tensor &target, int64_t
     const auto table = g_state.sampler.sample();
     ensure_device_state(input, (int)(n_random + n_specular));
     const auto scenes = g_state.ring.upload(table, input.device(), reinterpret_cast<void *>(stream));
-    return FusedLoss::apply(input, target, scenes, eps, l1_weight, eps_l1, stream);
+    return FusedLoss::apply(input, target, scenes, eps, l1_weight, eps_l1, stream, head);
 }
 
 // same with caller-provided scenes ([B,S,9] on the device)
 at::Tensor fused_loss_with_scenes(const at::Tensor &input, const at::Tensor &target, const at::Tensor &scenes, double eps,
-                                  double l1_weight, double eps_l1, int64_t stream)
+                                  double l1_weight, double eps_l1, int64_t stream, bool head)
 {
-    check_inputs(input, target);
+    check_inputs(input, target, head);
     TORCH_CHECK(scenes.dim() == 3 && scenes.size(0) == input.size(0) && scenes.size(2) == 9 && scenes.is_cuda() &&
                     scenes.scalar_type() == at::kFloat,
                 "scenes must be a [B,S,9] fp32 device tensor");
     std::lock_guard<std::mutex> lock(g_state.mu);
     ensure_device_state(input, (int)scenes.size(1));
-    return FusedLoss::apply(input, target, scenes.contiguous(), eps, l1_weight, eps_l1, stream);
+    return FusedLoss::apply(input, target, scenes.contiguous(), eps, l1_weight, eps_l1, stream, head);
 }
 
 // the sampler alone (host tensor) -- used by the bit-exactness tests

@@ -39,7 +39,6 @@ constexpr int kLossThreads = 256;      // K3 workgroup; 64 and 128 threads measu
 constexpr float kPi = 3.14159274101257324219f;  // float32(math.pi), renderers.py:20,27
 constexpr float kMinDot = 0.001f;      // renderers.py:48-52
 constexpr float kMinRough = 0.001f;    // renderers.py:87
-constexpr float kMinDen = 0.001f;      // renderers.py:26
 
 // ------------------------------------------------------------------------------------------
 // arithmetic primitives
@@ -92,7 +91,7 @@ __device__ __forceinline__ Recip length_rn(float x, float &seed)
 // constants the inner loop uses over and over therefore live in VGPRs (the empty asm makes
 // them opaque so the compiler cannot fold them back into literals).
 struct VConst {
-    float tiny;     // 0.001: the clamps of renderers.py:26, 48-52, 87
+    float tiny;     // 0.001: the clamps of renderers.py:26 (GGX denominator), 48-52 (dots), 87 (roughness)
     float pi, inv_pi;
     float ln2;
     float huge;     // 1e30, for sign()
@@ -642,9 +641,55 @@ __device__ __forceinline__ float signed_scale(float delta, float scale)
     return __builtin_amdgcn_fmed3f(delta * 1.0e30f, -1.0f, 1.0f) * scale;
 }
 
+// Network head folded into the loss (the north star's "normal-map decode"):
+// the generator's 9-channel output after tanh, layout normals_xy(0:2) | diffuse(2:5) |
+// roughness(5) | specular(6:9) (utils.py:49-53), is decoded exactly like
+// models.py:338-346 -> utils.py:73-98: normals = normalize(3 nx, 3 ny, 1), roughness repeated
+// to three channels, d/r/s mapped from [-1,1] to [0,1] by (x+1)/2.  The normal feeds NH, so its
+// normalisation reproduces the reference's rounding (exact dot, correctly rounded sqrt and
+// division) like the rest of the geometry.
+struct Head {
+    float nx, ny, nz;      // decoded unit normal
+    float inv_len;         // 1/|(3nx, 3ny, 1)|
+};
+
+__device__ __forceinline__ Head decode_head(const float e[9], Maps &m)
+{
+    Head h;
+    const float vx = e[0] * 3.0f, vy = e[1] * 3.0f;
+    float seed;
+    const Recip il = length_rn((vx * vx + vy * vy) + 1.0f, seed);   // sum(pow(v,2)) with v.z = 1
+    h.nx = div_rn(vx, il); h.ny = div_rn(vy, il); h.nz = div_rn(1.0f, il);
+    h.inv_len = il.y;
+    m.n[0] = h.nx; m.n[1] = h.ny; m.n[2] = h.nz;
+    const float r = (e[5] + 1.0f) * 0.5f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        m.d[k] = (e[2 + k] + 1.0f) * 0.5f;
+        m.r[k] = r;
+        m.s[k] = (e[6 + k] + 1.0f) * 0.5f;
+    }
+    return h;
+}
+
+// chain rule through decode_head: 12-channel gradient -> 9-channel gradient
+__device__ __forceinline__ void head_bwd(const Head &h, const Grad &g, float ge[9])
+{
+    // n = v/|v|: dL/dv = (g_n - n (n.g_n))/|v|, v = (3 nx, 3 ny, 1)
+    const float ng = fma_(h.nx, g.n[0], fma_(h.ny, g.n[1], h.nz * g.n[2]));
+    ge[0] = 3.0f * (fma_(-h.nx, ng, g.n[0]) * h.inv_len);
+    ge[1] = 3.0f * (fma_(-h.ny, ng, g.n[1]) * h.inv_len);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        ge[2 + k] = 0.5f * g.d[k];
+        ge[6 + k] = 0.5f * g.s[k];
+    }
+    ge[5] = 0.5f * ((g.r[0] + g.r[1]) + g.r[2]);
+}
+
 // One thread = one pixel (VEC = 1: the kernel is VALU-bound, wider loads measured no gain
 // and cost occupancy).  WITH_L1 adds SVBRDFL1Loss on the 24 values already in registers.
-template <bool WITH_GRAD, bool WITH_L1>
+template <bool WITH_GRAD, bool WITH_L1, bool HEAD>
 __global__ __launch_bounds__(kLossThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_rendering_loss(const float *__restrict__ input,
                                                                  const float *__restrict__ target,
                                                                  const float *__restrict__ scenes,
@@ -663,7 +708,16 @@ __global__ __launch_bounds__(kLossThreads) __attribute__((amdgpu_waves_per_eu(4,
     float lsum = 0.0f;
     if (active) {
         Maps in[1], tg[1];
-        load_maps<1>(input + (size_t)b * 12 * plane, plane, pix, in);
+        Head head;
+        if (HEAD) {     // input is the [B,9,H,W] post-tanh generator output
+            float e[9];
+            const float *__restrict__ ip = input + (size_t)b * 9 * plane + pix;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) e[k] = ip[(size_t)k * plane];
+            head = decode_head(e, in[0]);
+        } else {
+            load_maps<1>(input + (size_t)b * 12 * plane, plane, pix, in);
+        }
         load_maps<1>(target + (size_t)b * 12 * plane, plane, pix, tg);
         Grad acc;
         zero_grad(acc);
@@ -696,8 +750,16 @@ __global__ __launch_bounds__(kLossThreads) __attribute__((amdgpu_waves_per_eu(4,
             lsum = loss_scene_loop<3, WITH_GRAD>(mi, mt, x[0], y, scp, S, eps, inv_count, acc);
         if (WITH_L1) lsum = fma_(l1sum, l1.sum_scale, lsum);
         if (WITH_GRAD) {
-            const Grad out[1] = {acc};
-            store_grads<1>(grad_input + (size_t)b * 12 * plane, plane, pix, out);
+            if (HEAD) {
+                float ge[9];
+                head_bwd(head, acc, ge);
+                float *__restrict__ gp = grad_input + (size_t)b * 9 * plane + pix;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) gp[(size_t)k * plane] = ge[k];
+            } else {
+                const Grad out[1] = {acc};
+                store_grads<1>(grad_input + (size_t)b * 12 * plane, plane, pix, out);
+            }
         }
     }
     lsum = wave_sum(lsum);
@@ -898,7 +960,7 @@ size_t svbrdf_rendering_loss_workspace_bytes(int B, int S, int H, int W)
     return (kLossSlots + 1) * sizeof(unsigned long long);   // sharded fixed-point accumulators + ticket
 }
 
-static int loss_impl(const char *who, const float *input, const float *target, const float *scenes,
+static int loss_impl(const char *who, bool head, const float *input, const float *target, const float *scenes,
                      const float *xrow, float eps, float l1_weight, float eps_l1, float *loss_out,
                      float *grad_input, void *workspace, size_t workspace_bytes, int B, int S, int H, int W,
                      void *stream)
@@ -928,15 +990,19 @@ static int loss_impl(const char *who, const float *input, const float *target, c
     if ((unsigned long long)grid.x * grid.y >= (1ULL << 16) * kLossSlots)
         return fail(SVBRDF_ERR_DIMS, "loss: too many workgroups for the arrival counters");
     const L1Params l1{l1_weight * (float)S, (float)((double)l1_weight / ((double)B * 3.0 * (double)plane)), eps_l1};
-#define SVBRDF_LAUNCH_K3(G, L)                                                                              \
-    hipLaunchKernelGGL((k_rendering_loss<G, L>), grid, block, 0, st, input, target, scenes, xrow, eps,      \
+#define SVBRDF_LAUNCH_K3(G, L, HD)                                                                          \
+    hipLaunchKernelGGL((k_rendering_loss<G, L, HD>), grid, block, 0, st, input, target, scenes, xrow, eps,  \
                        inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, S, H, W)
-    if (l1_weight != 0.0f) {
-        if (grad_input) SVBRDF_LAUNCH_K3(true, true);
-        else SVBRDF_LAUNCH_K3(false, true);
-    } else {
-        if (grad_input) SVBRDF_LAUNCH_K3(true, false);
-        else SVBRDF_LAUNCH_K3(false, false);
+    const int variant = (head ? 4 : 0) | (l1_weight != 0.0f ? 2 : 0) | (grad_input ? 1 : 0);
+    switch (variant) {
+    case 0: SVBRDF_LAUNCH_K3(false, false, false); break;
+    case 1: SVBRDF_LAUNCH_K3(true, false, false); break;
+    case 2: SVBRDF_LAUNCH_K3(false, true, false); break;
+    case 3: SVBRDF_LAUNCH_K3(true, true, false); break;
+    case 4: SVBRDF_LAUNCH_K3(false, false, true); break;
+    case 5: SVBRDF_LAUNCH_K3(true, false, true); break;
+    case 6: SVBRDF_LAUNCH_K3(false, true, true); break;
+    default: SVBRDF_LAUNCH_K3(true, true, true); break;
     }
 #undef SVBRDF_LAUNCH_K3
     return launch_status(who);
@@ -947,7 +1013,7 @@ int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *target, const
                                   void *workspace, size_t workspace_bytes, int B, int S, int H, int W,
                                   void *stream)
 {
-    return loss_impl("rendering_loss", input, target, scenes, xrow, eps, 0.0f, 0.01f, loss_out, grad_input,
+    return loss_impl("rendering_loss", false, input, target, scenes, xrow, eps, 0.0f, 0.01f, loss_out, grad_input,
                      workspace, workspace_bytes, B, S, H, W, stream);
 }
 
@@ -956,8 +1022,16 @@ int svbrdf_mixed_loss_fwd_bwd(const float *input, const float *target, const flo
                               float *grad_input, void *workspace, size_t workspace_bytes, int B, int S, int H,
                               int W, void *stream)
 {
-    return loss_impl("mixed_loss", input, target, scenes, xrow, eps_render, l1_weight, eps_l1, loss_out,
+    return loss_impl("mixed_loss", false, input, target, scenes, xrow, eps_render, l1_weight, eps_l1, loss_out,
                      grad_input, workspace, workspace_bytes, B, S, H, W, stream);
+}
+
+int svbrdf_head_loss_fwd_bwd(const float *encoded9, const float *target, const float *scenes, const float *xrow,
+                             float eps_render, float l1_weight, float eps_l1, float *loss_out, float *grad_encoded9,
+                             void *workspace, size_t workspace_bytes, int B, int S, int H, int W, void *stream)
+{
+    return loss_impl("head_loss", true, encoded9, target, scenes, xrow, eps_render, l1_weight, eps_l1, loss_out,
+                     grad_encoded9, workspace, workspace_bytes, B, S, H, W, stream);
 }
 
 int svbrdf_scale_inplace(float *data, const float *scale_dev, size_t n, void *stream)

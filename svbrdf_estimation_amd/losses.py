@@ -33,11 +33,13 @@ class _FusedRenderingLoss(torch.autograd.Function):
     """K3 behind autograd: the kernel already produces d loss/d input for upstream grad 1."""
 
     @staticmethod
-    def forward(ctx, input, target, scenes, eps, l1_weight=0.0, eps_l1=0.01):
+    def forward(ctx, input, target, scenes, eps, l1_weight=0.0, eps_l1=0.01, head=False):
         need_in = ctx.needs_input_grad[0]
         need_tg = ctx.needs_input_grad[1]
+        if head and need_tg:
+            raise RuntimeError("the head-fused loss has no gradient w.r.t. the target maps")
         loss, grad_in = _native.rendering_loss(input, target, scenes, eps, want_grad=need_in,
-                                               l1_weight=l1_weight, eps_l1=eps_l1)
+                                               l1_weight=l1_weight, eps_l1=eps_l1, head=head)
         grad_tg = None
         if need_tg:
             # every term is |g(a) - g(b)|, symmetric: the target's gradient is the same kernel, roles swapped
@@ -59,7 +61,7 @@ class _FusedRenderingLoss(torch.autograd.Function):
         for g in (grad_in, grad_tg):
             if g is not None:
                 _native.scale_inplace_(g, scale)
-        return grad_in, grad_tg, None, None, None, None
+        return grad_in, grad_tg, None, None, None, None, None
 
 
 def _check_shapes(input, target):
@@ -92,22 +94,26 @@ class RenderingLoss(nn.Module):
     def uses_fused_kernel(self):
         return isinstance(self.renderer, renderers.LocalRenderer)
 
-    def _forward_fused(self, input, target, l1_weight=0.0, eps_l1=0.01):
-        _check_shapes(input, target)
+    def _forward_fused(self, input, target, l1_weight=0.0, eps_l1=0.01, head=False):
+        if head:
+            if input.dim() != 4 or target.dim() != 4 or input.shape[1] != 9 or target.shape[1] != 12:
+                raise ValueError("head-fused loss needs input [B,9,H,W] and target [B,12,H,W]")
+        else:
+            _check_shapes(input, target)
         ext = _hostext.module() if input.is_cuda else None
         if ext is not None and input.dtype == torch.float32 and target.dtype == torch.float32 \
                 and input.device.index == torch.cuda.current_device():
             # native host path: same draws, same kernels, no interpreter in the loop
             return ext.fused_loss(input, target, int(self.random_configuration_count),
                                   int(self.specular_configuration_count), float(self.epsilon_render),
-                                  float(l1_weight), float(eps_l1), _native._raw_stream(input.device))
+                                  float(l1_weight), float(eps_l1), _native._raw_stream(input.device), bool(head))
         table = self.sample_scene_table(input.shape[0])
         if not input.is_cuda:
             raise _native.NativeLibraryError(
                 "RenderingLoss with the MI355X LocalRenderer needs tensors on a ROCm device "
                 "(got %s); there is no CPU fallback" % input.device)
         return _FusedRenderingLoss.apply(input, target, _native.upload_scene_table(table, input.device),
-                                         self.epsilon_render, float(l1_weight), float(eps_l1))
+                                         self.epsilon_render, float(l1_weight), float(eps_l1), bool(head))
 
     def _forward_plugin(self, input, target):
         """Generic plugin path for a foreign renderer object (losses.py:29-52 semantics)."""
@@ -140,3 +146,33 @@ class MixedLoss(nn.Module):
             return self.rendering_loss._forward_fused(input, target, l1_weight=float(self.l1_weight),
                                                       eps_l1=self.l1_loss.epsilon_l1)
         return self.l1_weight * self.l1_loss(input, target) + self.rendering_loss(input, target)
+
+
+def decode_head(encoded9):
+    """The network head of the reference's models (models.py:338-346): generator output after tanh,
+    [..,9,H,W] in [-1,1] -> [..,12,H,W] maps (unit normals; diffuse, roughness x3, specular in [0,1])."""
+    maps = utils.decode_svbrdf(encoded9)
+    n, d, r, s = torch.split(maps, (3, 3, 3, 3), dim=-3)
+    return utils.pack_svbrdf(n, utils.encode_as_unit_interval(d), utils.encode_as_unit_interval(r),
+                             utils.encode_as_unit_interval(s))
+
+
+class FusedHeadLoss(nn.Module):
+    """``MixedLoss(renderer, l1_weight)(decode_head(encoded9), target)`` in one
+    kernel -- the head decode (normal-map decode, roughness repeat, range maps), both renderings, the
+    L1 and rendering losses and the gradient w.r.t. the NINE encoded channels.  The model returns
+    ``tanh(generator(x))`` and skips its own decode; use ``decode_head`` when the maps themselves are
+    needed (validation images).  ``l1_weight=0`` gives the pure rendering loss."""
+
+    def __init__(self, renderer, l1_weight=0.1):
+        super().__init__()
+        self.l1_weight = l1_weight
+        self.l1_loss = SVBRDFL1Loss()
+        self.rendering_loss = RenderingLoss(renderer)
+
+    def forward(self, encoded9, target):
+        if self.rendering_loss.uses_fused_kernel() and encoded9.is_cuda:
+            return self.rendering_loss._forward_fused(encoded9, target, l1_weight=float(self.l1_weight),
+                                                      eps_l1=self.l1_loss.epsilon_l1, head=True)
+        maps = decode_head(encoded9)
+        return self.l1_weight * self.l1_loss(maps, target) + self.rendering_loss(maps, target)

@@ -299,6 +299,36 @@ def g10_render_inputs():
     save("g10_render_inputs.npz", **arrays)
 
 
+def g11_head_loss():
+    """row f1: the model head (models.py:338-346) + MixedLoss, gradient w.r.t. the 9 encoded channels"""
+    B, H = 2, 24
+    enc = (synth.uniform01(601, (B, 9, H, H)) * np.float32(1.8) - np.float32(0.9)).astype(np.float32)
+    enc[:, 0:2] *= np.float32(0.25)                          # moderate normal tilt, like a trained net
+    tgt = synth.make_maps(602, B, H, tiled_roughness=True)
+
+    def head(t):
+        sv = ref_utils.decode_svbrdf(t)
+        n, d, r, s = ref_utils.unpack_svbrdf(sv)
+        return ref_utils.pack_svbrdf(n, ref_utils.encode_as_unit_interval(d), ref_utils.encode_as_unit_interval(r),
+                                     ref_utils.encode_as_unit_interval(s))
+    out = {}
+    for tag, w in (("mixed", 0.1), ("render", 0.0)):
+        x = torch.from_numpy(enc).clone().requires_grad_(True)
+        maps = head(x)
+        torch.manual_seed(17)
+        with _Recorder() as rec:
+            if w:
+                loss = ref_losses.MixedLoss(ref_renderers.LocalRenderer(), l1_weight=w)(maps, torch.from_numpy(tgt))
+            else:
+                loss = ref_losses.RenderingLoss(ref_renderers.LocalRenderer())(maps, torch.from_numpy(tgt))
+        loss.backward()
+        out[tag + "_loss"] = np.float32(loss.item())
+        out[tag + "_grad9"] = x.grad.numpy()
+        out["scenes"] = rec.table()
+        out["decoded12"] = maps.detach().numpy()
+    save("g11_head_loss.npz", enc9=enc, target=tgt, rng_seed=np.int64(17), **out)
+
+
 def g9_kat():
     R = ref_renderers.LocalRenderer()
     out = {}
@@ -333,6 +363,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--only-render-inputs":  # row f3, added later
         g10_render_inputs()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-head-loss":      # row f1, added later
+        g11_head_loss()
+        return
     g1_render_64()
     g2_lattice(256, 8, 111)
     g2_lattice(512, 16, 112)
@@ -345,6 +378,7 @@ def main():
     g8_utils()
     g9_kat()
     g10_render_inputs()
+    g11_head_loss()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "mworchel/svbrdf-estimation @ /root/reference (development/multiImage_pytorch)",

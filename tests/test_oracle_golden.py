@@ -137,3 +137,14 @@ def test_bad_dims_rejected(oracle):
     with pytest.raises(RuntimeError):
         oracle.render_fwd(np.zeros((1, 12, 4, 8), np.float32), np.zeros((1, 1, 9), np.float32),
                           xrow=np.zeros(8, np.float32))
+
+
+def test_head_decode_and_head_loss(oracle, golden):
+    """row f1: oracle restatement of the model head (models.py:338-346) + mixed loss vs the reference"""
+    g = golden("g11_head_loss.npz")
+    np.testing.assert_allclose(oracle.head_decode(g["enc9"]), g["decoded12"], rtol=3e-7, atol=1e-7)
+    for tag, w in (("mixed", 0.1), ("render", 0.0)):
+        loss, grad = oracle.head_loss(g["enc9"], g["target"], g["scenes"], w)
+        _, g64 = oracle.head_loss(g["enc9"], g["target"], g["scenes"], w, f64=True)
+        assert_loss_close(loss, g[tag + "_loss"], tag)
+        assert_grad_close(grad, g[tag + "_grad9"], tag + " grad9", f64=g64)
