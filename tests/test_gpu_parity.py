@@ -527,3 +527,19 @@ def test_head_fused_loss_golden(dev, native, oracle, golden):
     assert_grad_close(_np(res[0][1]), g["mixed_grad9"], "FusedHeadLoss grad", f64=g64)
     with pytest.raises(Exception):
         losses.FusedHeadLoss(renderers.LocalRenderer())(d_enc, d_tg.clone().requires_grad_(True)).backward()
+
+
+# ---------------------------------------------------------------- row f4: training harness on the GPU
+
+def test_training_harness_single_gpu_loss_decreases(dev, tmp_path):
+    """train.py, one GPU: synthetic SVBRDFs, photos synthesised by K1, U-Net (stock), fused MixedLoss and
+    the head-fused variant; a few Adam steps at a raised learning rate must lower the loss"""
+    import train
+    for extra in ([], ["--fused-head"]):
+        args = train.parse_args(["--steps", "12", "--warmup", "2", "--batch", "2", "--workers", "0", "--lr", "2e-4",
+                                 "--samples", "2"] + extra)
+        res = train.run(args)
+        assert np.isfinite(res["loss_last_quarter"]) and res["loss_last_quarter"] < res["loss_first_quarter"], res
+    args = train.parse_args(["--model", "multi", "--views", "2", "--steps", "3", "--warmup", "1", "--batch", "1",
+                             "--workers", "0", "--samples", "2"])
+    assert np.isfinite(train.run(args)["loss_last_quarter"])

@@ -1,0 +1,91 @@
+"""CPU: row f4 -- the re-stated Deschaintre network.  Parameter counts are the reference's (SURVEY.md
+section 2 probe), and where the reference is mounted (the build container) the forward pass is
+compared with the reference's own models after converting its state dict."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference/development/multiImage_pytorch"
+
+
+def test_parameter_counts_match_the_reference():
+    from svbrdf_estimation_amd.training import models
+    count = lambda m: sum(p.numel() for p in m.parameters())
+    assert count(models.SingleViewModel(use_coords=False)) == 79985621
+    assert count(models.MultiViewModel(use_coords=False)) == 80262042
+    assert count(models.SingleViewModel(use_coords=True)) == 79985621 + 2 * (64 * 16 + 128)
+
+
+def _load_reference_models():
+    sys.dont_write_bytecode = True
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    sys.modules.setdefault("pyredner", types.ModuleType("pyredner"))
+    saved = {k: sys.modules.get(k) for k in ("utils", "models")}
+    sys.path.insert(0, REF)
+    try:
+        for k in ("utils", "models"):
+            sys.modules.pop(k, None)
+        import models as ref_models
+        return ref_models
+    finally:
+        sys.path.remove(REF)
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference is only mounted in the build container")
+@pytest.mark.parametrize("use_coords", [True, False])
+def test_forward_equals_reference_models(use_coords):
+    from svbrdf_estimation_amd.training import models
+    ref_models = _load_reference_models()
+    torch.manual_seed(0)
+    ref = ref_models.SingleViewModel(use_coords=use_coords).eval()
+    mine = models.SingleViewModel(use_coords=use_coords).eval()
+    mine.load_state_dict(models.convert_reference_state_dict(ref.state_dict()))
+    x = torch.rand(1, 3, 256, 256)
+    with torch.no_grad():
+        a, b = ref(x), mine(x)
+    assert a.shape == b.shape == (1, 12, 256, 256)
+    np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=1e-5, atol=1e-6)
+    enc = models.SingleViewModel(use_coords=use_coords, decode=False).eval()
+    enc.load_state_dict(mine.state_dict())
+    with torch.no_grad():
+        assert enc(x).shape == (1, 9, 256, 256)
+    if use_coords:       # multi-view: N photos, max-pooled; the reference loops over photos, this batches them
+        torch.manual_seed(1)
+        ref_mv = ref_models.MultiViewModel(use_coords=True).eval()
+        mine_mv = models.MultiViewModel(use_coords=True).eval()
+        mine_mv.load_state_dict(models.convert_reference_state_dict(ref_mv.state_dict()))
+        xs = torch.rand(1, 2, 3, 256, 256)
+        with torch.no_grad():
+            # batched generator pass vs the reference's per-photo loop: different conv blocking, fp32 noise
+            np.testing.assert_allclose(mine_mv(xs).numpy(), ref_mv(xs).numpy(), rtol=1e-4, atol=3e-5)
+
+
+def test_tiled_png_round_trip(tmp_path):
+    from svbrdf_estimation_amd.training import data
+    torch.manual_seed(3)
+    H, n = 32, 2
+    photos = torch.rand(n, 3, H, H)
+    normals = torch.nn.functional.normalize(torch.randn(3, H, H) * 0.3 + torch.tensor([0, 0, 1.0]).view(3, 1, 1), dim=0)
+    svbrdf = torch.cat((normals, torch.rand(9, H, H)), dim=0)
+    path = str(tmp_path / "sample.png")
+    data.write_tiled_png(path, photos, svbrdf)
+    p2, s2 = data.read_tiled_png(path, n)
+    assert p2.shape == (n, 3, H, H) and s2.shape == (12, H, H)
+    assert (p2 - photos).abs().max() <= 0.5 / 255 + 1e-6
+    assert (s2[3:] - svbrdf[3:]).abs().max() <= 0.5 / 255 + 1e-6
+    assert (s2[:3] - svbrdf[:3]).abs().max() <= 1.0 / 255 + 1e-6          # normals stored in [0,1]
+    ds = data.TiledPngDataset(str(tmp_path), image_size=16, image_count=n, used_image_count=1)
+    item = ds[0]
+    assert item["inputs"].shape == (1, 3, 16, 16) and item["svbrdf"].shape == (12, 16, 16)
+    assert torch.allclose(item["inputs"][0], p2[1, :, :16, :16] ** 2.2)  # last photo, gamma-decoded
+    with pytest.raises(ValueError):
+        data.read_tiled_png(path, 3)
+    syn = data.SyntheticSvbrdfDataset(4, image_size=8, seed=1)
+    assert len(syn) == 4 and syn[2]["svbrdf"].shape == (12, 8, 8) and torch.equal(syn[2]["svbrdf"], syn[2]["svbrdf"])

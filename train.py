@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""train.py -- data-parallel training harness around the rendering-loss engine.
+
+One process per GPU (torchrun), batch sharded by rank with a DistributedSampler, stock
+DistributedDataParallel for the U-Net: its ~320 MB of fp32 gradients per step are all-reduced by
+RCCL over xGMI in buckets overlapped with the backward pass (backend "nccl" is RCCL on ROCm).  The
+rendering / mixed loss itself needs no collective: each rank evaluates it on its shard with its own
+scene RNG stream (seed + rank) and DDP's gradient averaging makes the result the global-batch
+gradient.  What the reference's main.py:56-150 does on one GPU, in the reference's order:
+batch -> (synthesise missing photos) -> model -> MixedLoss -> backward -> Adam(lr 1e-5).
+
+  python train.py --steps 20                                   # 1 GPU, synthetic SVBRDFs, single-view
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py --batch 8 --steps 100
+  python train.py --model multi --views 5 --batch 16           # BASELINE config 4
+  python train.py --size 512 --random-scenes 11 --specular-scenes 21   # BASELINE config 5 (per GPU)
+  python train.py --data /path/to/tiled_pngs --image-count 10  # Deschaintre tiled-PNG samples
+
+Prints one JSON line per run on rank 0 (end-to-end patches/s, mean loss of the first/last steps).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--data", default="synthetic", help="'synthetic' or a directory of tiled PNG samples")
+    ap.add_argument("--image-count", type=int, default=10, help="photos stored per tiled PNG")
+    ap.add_argument("--model", choices=("single", "multi"), default="single")
+    ap.add_argument("--views", type=int, default=1, help="input photos per sample (multi-view: N)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--lr", type=float, default=1e-5)                    # main.py:74
+    ap.add_argument("--l1-weight", type=float, default=0.1)              # losses.py:55
+    ap.add_argument("--random-scenes", type=int, default=3)              # losses.py:26
+    ap.add_argument("--specular-scenes", type=int, default=6)            # losses.py:27
+    ap.add_argument("--loss", choices=("mixed", "rendering", "l1"), default="mixed")
+    ap.add_argument("--fused-head", action="store_true", help="model returns 9 channels, head decoded in the loss kernel")
+    ap.add_argument("--no-coords", action="store_true")
+    ap.add_argument("--samples", type=int, default=0, help="synthetic dataset length (default: enough for --steps)")
+    ap.add_argument("--workers", type=int, default=2)
+    ap.add_argument("--seed", type=int, default=313)                     # utils.py:7
+    ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"))
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl on cuda, gloo on cpu)")
+    ap.add_argument("--save", default=None, help="write a checkpoint (model + optimizer state) here at the end")
+    return ap.parse_args(argv)
+
+
+def run(args):
+    from svbrdf_estimation_amd import distributed, losses, renderers, utils
+    from svbrdf_estimation_amd.training import data, models
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    on_gpu = args.device == "cuda"
+    if on_gpu:
+        assert torch.cuda.is_available(), "no ROCm device visible"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        if args.loss != "l1":
+            raise SystemExit("the rendering loss has no CPU path; --device cpu only supports --loss l1 (plumbing tests)")
+        dev = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = args.backend or ("nccl" if on_gpu else "gloo")
+        dist.init_process_group(backend=backend, **({"device_id": dev} if on_gpu else {}))
+
+    utils.enable_deterministic_random_engine(distributed.rank_seed(args.seed, rank))   # per-rank scene RNG
+    decode = not args.fused_head
+    if args.model == "multi":
+        net = models.MultiViewModel(use_coords=not args.no_coords, decode=decode)
+    else:
+        net = models.SingleViewModel(use_coords=not args.no_coords, decode=decode)
+    # identical initial weights on every rank: DDP broadcasts rank 0's parameters at construction
+    net = net.to(dev).train()
+    model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank] if on_gpu else None) \
+        if world > 1 else net
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
+
+    if args.loss == "l1":
+        loss_fn = losses.SVBRDFL1Loss()
+        if args.fused_head:
+            raise SystemExit("--fused-head needs the rendering or mixed loss")
+    else:
+        weight = args.l1_weight if args.loss == "mixed" else 0.0
+        loss_fn = (losses.FusedHeadLoss if args.fused_head else losses.MixedLoss)(renderers.LocalRenderer(), weight)
+        loss_fn.rendering_loss.random_configuration_count = args.random_scenes
+        loss_fn.rendering_loss.specular_configuration_count = args.specular_scenes
+
+    total_steps = args.warmup + args.steps
+    if args.data == "synthetic":
+        n = args.samples or total_steps * args.batch * world
+        dataset = data.SyntheticSvbrdfDataset(n, image_size=args.size, seed=args.seed)
+    else:
+        dataset = data.TiledPngDataset(args.data, image_size=args.size, image_count=args.image_count,
+                                       used_image_count=args.views)
+    sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True,
+                                                              seed=args.seed, drop_last=True) if world > 1 else None
+    loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch, sampler=sampler, shuffle=sampler is None,
+                                         num_workers=args.workers, pin_memory=on_gpu, drop_last=True,
+                                         persistent_workers=args.workers > 0)
+
+    def batches():
+        epoch = 0
+        while True:
+            if sampler is not None:
+                sampler.set_epoch(epoch)
+            for b in loader:
+                yield b
+            epoch += 1
+
+    losses_seen, t0, it = [], None, batches()
+    for step in range(total_steps):
+        if step == args.warmup:
+            if on_gpu:
+                torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+        batch = next(it)
+        svbrdf = batch["svbrdf"].to(dev, non_blocking=True)
+        stored = batch["inputs"].to(dev, non_blocking=True)
+        if on_gpu:
+            photos = data.complete_inputs(stored, svbrdf, args.views)           # K1: missing photos, whole batch
+        else:                                                                    # CPU plumbing runs: constant photos
+            photos = torch.cat((stored, svbrdf[:, None, 3:6].expand(-1, max(args.views - stored.shape[1], 0), -1, -1, -1)), 1)
+        net_in = photos if args.model == "multi" else photos[:, 0]
+        optimizer.zero_grad(set_to_none=True)
+        out = model(net_in)
+        loss = loss_fn(out, svbrdf)
+        loss.backward()
+        optimizer.step()
+        losses_seen.append(loss.detach())
+    if on_gpu:
+        torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    vals = torch.stack(losses_seen).float()
+    first, last = vals[: max(1, len(vals) // 4)].mean(), vals[-max(1, len(vals) // 4):].mean()
+    first, last = distributed.global_mean(first).item(), distributed.global_mean(last).item()
+    result = {"metric": "end-to-end training patches/s (U-Net + %s loss)" % args.loss,
+              "value": world * args.batch * args.steps / elapsed, "unit": "patches/s", "n_gpus": world,
+              "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps, "warmup": args.warmup,
+              "loss_first_quarter": first, "loss_last_quarter": last,
+              "config": {"model": args.model, "views": args.views, "size": args.size, "per_gpu_batch": args.batch,
+                         "scenes": args.random_scenes + args.specular_scenes, "fused_head": bool(args.fused_head),
+                         "data": args.data if args.data == "synthetic" else "tiled-png"}}
+    if rank == 0:
+        if args.save:
+            torch.save({"model_state_dict": net.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+                        "model_type": args.model, "use_coords": not args.no_coords}, args.save)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    run(parse_args())
