@@ -9,7 +9,9 @@ from k3_sweep import maps, timeit
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     gen = torch.Generator().manual_seed(1)
-    for (B, H, S, tied) in [(8, 256, 9, True), (8, 256, 9, False), (8, 256, 1, True), (72, 256, 1, True), (32, 256, 9, True), (8, 512, 32, True)]:
+    # B=288/576, S=1: 0.9-1.8 GB of maps per launch, far beyond the 256 MiB Infinity Cache -> genuine HBM rates
+    for (B, H, S, tied) in [(8, 256, 9, True), (8, 256, 9, False), (8, 256, 1, True), (72, 256, 1, True),
+                            (288, 256, 1, True), (576, 256, 1, False), (32, 256, 9, True), (8, 512, 32, True)]:
         m = maps(B, H, gen, tied).to(dev)
         torch.manual_seed(0)
         table = environment.BatchSceneSampler(B, S // 3, S - S // 3).sample().to(dev)
