@@ -12,7 +12,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "lib", "libsvbrdf_hip.so")
+# SVBRDF_HIP_LIB: load another build of the same ABI (ablation/experiment builds of tools/); default in-tree
+_SO = os.environ.get("SVBRDF_HIP_LIB") or os.path.join(_HERE, "lib", "libsvbrdf_hip.so")
 ABI_VERSION = 1
 
 _lock = threading.Lock()

@@ -63,12 +63,23 @@ __device__ __forceinline__ float rsq_(float x) { return __builtin_amdgcn_rsqf(x)
 // 1e-3 <~ b <~ 1e3 (lengths of camera/light offsets).  svbrdf_debug_check_arith() compares
 // both primitives with the IEEE-correct `/` and sqrtf on the device: 0 mismatches in
 // 3 x 2^31 operand pairs (tests/test_gpu_parity.py).
+// Timing experiments only (tools/ablate.sh builds separate libraries with -DSVBRDF_ABLATE=n; results
+// are WRONG by construction): 1 = inexact geometry (rsq*x instead of exact sqrt/division),
+// 2 = no target shading, 3 = no logs in the loss, 4 = no adjoint, 5 = no GGX/Smith lobe.
+#ifndef SVBRDF_ABLATE
+#define SVBRDF_ABLATE 0
+#endif
+#ifndef SVBRDF_K3_MIN_WAVES
+#define SVBRDF_K3_MIN_WAVES 4      // waves/SIMD the register allocator must leave room for (128 VGPRs)
+#endif
+
 struct Recip {
     float b, y;
 };
 __device__ __forceinline__ float div_rn(float a, const Recip &r)
 {
     const float q = a * r.y;
+    if (SVBRDF_ABLATE == 1) return q;
     return fma_(fma_(-r.b, q, a), r.y, q);
 }
 
@@ -80,9 +91,10 @@ __device__ __forceinline__ Recip length_rn(float x, float &seed)
 {
     const float y = rsq_(x);
     const float g = x * y;
+    seed = y;
+    if (SVBRDF_ABLATE == 1) return Recip{g, y};
     const float len = fma_(fma_(-g, g, x), 0.5f * y, g);
     const float e = fma_(-len, y, 1.0f);
-    seed = y;
     return Recip{len, fma_(e, y, y)};
 }
 
@@ -101,9 +113,14 @@ __device__ __forceinline__ float vreg(float c)
     asm volatile("" : "+v"(c));
     return c;
 }
+#ifndef SVBRDF_VCONST
+#define SVBRDF_VCONST 1
+#endif
 __device__ __forceinline__ VConst make_vconst()
 {
-    return VConst{vreg(kMinDot), vreg(kPi), vreg(1.0f / kPi), vreg(0.693147180559945309417f), vreg(1.0e30f)};
+    if (SVBRDF_VCONST)
+        return VConst{vreg(kMinDot), vreg(kPi), vreg(1.0f / kPi), vreg(0.693147180559945309417f), vreg(1.0e30f)};
+    return VConst{kMinDot, kPi, 1.0f / kPi, 0.693147180559945309417f, 1.0e30f};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -226,6 +243,10 @@ template <bool BWD>
 __device__ __forceinline__ Lobe lobe(const VConst &K, float A, const Dots &d)
 {
     Lobe l;
+    if (SVBRDF_ABLATE == 5) {
+        l.GD = A * d.uV; l.KA = d.uL; l.KV = A; l.KL = d.NH2; l.KN = d.oN;
+        return l;
+    }
     const float xV = fma_(A, d.uV, 1.0f), xL = fma_(A, d.uL, 1.0f);
     // sqrt as x*rsq(x) in the forward-only and the forward+backward instantiation alike, so
     // that input and target shading are the SAME arithmetic (identical maps -> loss exactly 0)
@@ -567,12 +588,13 @@ constexpr unsigned long long kLossSumMask = (1ULL << kLossCountShift) - 1;
 
 // one (pixel, scene) of the fused loss: both shadings, log/L1, adjoint of the input shading
 template <int NL, bool WITH_GRAD>
-__device__ __forceinline__ void loss_pixel_scene(const VConst &K, const float sc[9], float x, float y, const MapK &mi,
+__device__ __forceinline__ void loss_pixel_scene(const VConst &K, const Geom &g, const MapK &mi,
                                                  const MapK &mt, float eps, float inv_count, float &lsum, Grad &acc)
 {
-    const Geom g = geometry(K, sc, x, y);
     float rt[3];
-    {
+    if (SVBRDF_ABLATE == 2) {
+        rt[0] = mt.dpi[0] * g.p; rt[1] = mt.dpi[1] * g.p; rt[2] = mt.dpi[2] * g.p;
+    } else {
         const Dots dt = dots(K, g, mt);
         Lobe lt[NL];
         float Ft[3], ft[3];
@@ -587,44 +609,69 @@ __device__ __forceinline__ void loss_pixel_scene(const VConst &K, const float sc
         // losses.py:46-50: |log(ri + eps) - log(rt + eps)|, v_log_f32 = log2.  (Merging the two
         // logs into log2(at * rcp(ai)) was measured: no gain, and it perturbs near-zero deltas.)
         const float ai = ri[k] + eps, at = rt[k] + eps;
-        const float delta = K.ln2 * (__builtin_amdgcn_logf(ai) - __builtin_amdgcn_logf(at));
+        const float delta = (SVBRDF_ABLATE == 3) ? (ai - at)
+                                                 : K.ln2 * (__builtin_amdgcn_logf(ai) - __builtin_amdgcn_logf(at));
         lsum += fabsf(delta);
         // d|delta|/d ri = sign(delta)/(N*ai), sign(0) = 0 as in torch
         const float sg = __builtin_amdgcn_fmed3f(delta * K.huge, -1.0f, 1.0f);
         g_rad[k] = sg * (inv_count * rcp_(ai));
     }
-    if (WITH_GRAD) shade_bwd<NL>(K, g, mi, di, li, Fi, fi, g_rad, acc);
+    if (SVBRDF_ABLATE == 4) {
+        acc.n[0] += g_rad[0]; acc.n[1] += g_rad[1]; acc.n[2] += g_rad[2];
+    } else if (WITH_GRAD) {
+        shade_bwd<NL>(K, g, mi, di, li, Fi, fi, g_rad, acc);
+    }
 }
 
-// Scene loop of K3, unrolled by two with the scene scalars double-buffered: the loads of
-// render s+1 are issued before the arithmetic of render s (sched_barrier keeps them there)
-// so their latency never sits on the critical path.
+// Scene loop of K3, software-pipelined: the geometry of render s+1 (three rsq-headed dependent
+// chains: lengths -> reciprocals -> quotients) is computed in the same iteration as the
+// shading / loss / adjoint of render s.  The two are independent instruction streams, which gives
+// the scheduler work to put behind the transcendentals' latency (measured: a v_rsq/v_rcp whose
+// result is consumed right away costs ~11 plain VALU slots, tools/valu_mix.hip).
+//
+// Where the nine scene scalars of a render come from is a register-pressure question, decided by
+// measurement (config 2, us per launch):            forward+adjoint   forward only
+//   LDS stage (one copy per workgroup, ds_read)          59.1             39.8
+//   global loads, double-buffered two renders ahead      56.5             43.8
+// The adjoint kernel sits at the 128-VGPR limit of 4 waves/SIMD and spills a little either way; the
+// LDS variant keeps the scalars live across the interleaved streams and spills more.  So: LDS for
+// the forward-only kernels, prefetched global loads for the forward+adjoint kernels.
 template <int NL, bool WITH_GRAD>
 __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt, float x, float y,
-                                                 const float *__restrict__ scp, int S, float eps, float inv_count,
-                                                 Grad &acc)
+                                                 const float *__restrict__ scp, const float *sc_lds, int S,
+                                                 float eps, float inv_count, Grad &acc)
 {
     float lsum = 0.0f;
     const VConst K = make_vconst();
     eps = vreg(eps);
     inv_count = vreg(inv_count);
-    float scA[9], scB[9];
-    load_scene(scp, scA);
-    for (int s = 0;; s += 2, scp += 18) {
-        // A wait on these loads is placed by the compiler at the first use of the buffer:
-        // consume the current buffer FIRST, only then issue the loads for the other one.
-        asm volatile("" ::"s"(scA[0]), "s"(scA[8]));
-        const bool moreB = s + 1 < S;
-        load_scene(scp + (moreB ? 9 : 0), scB);
-        __builtin_amdgcn_sched_barrier(0);
-        loss_pixel_scene<NL, WITH_GRAD>(K, scA, x, y, mi, mt, eps, inv_count, lsum, acc);
-        if (!moreB) break;
-        asm volatile("" ::"s"(scB[0]), "s"(scB[8]));
-        const bool moreA = s + 2 < S;
-        load_scene(scp + (moreA ? 18 : 9), scA);
-        __builtin_amdgcn_sched_barrier(0);
-        loss_pixel_scene<NL, WITH_GRAD>(K, scB, x, y, mi, mt, eps, inv_count, lsum, acc);
-        if (!moreA) break;
+    float sc[9];
+    if (WITH_GRAD) {
+        load_scene(scp, sc);
+        Geom g_next = geometry(K, sc, x, y);                     // render 0
+        load_scene(scp + (S > 1 ? 9 : 0), sc);                   // scalars of render 1
+        for (int s = 0; s < S; ++s) {
+            const Geom g = g_next;
+            asm volatile("" ::"s"(sc[0]), "s"(sc[8]));           // the wait for sc lands here, before the next loads
+            float cur[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) cur[i] = sc[i];
+            load_scene(scp + (s + 2 < S ? 18 : (s + 1 < S ? 9 : 0)), sc);
+            scp += (s + 1 < S) ? 9 : 0;
+            __builtin_amdgcn_sched_barrier(0);
+            // two independent streams from here to the end of the iteration:
+            g_next = geometry(K, cur, x, y);                     // render s+1 (a harmless repeat on the last pass)
+            loss_pixel_scene<NL, WITH_GRAD>(K, g, mi, mt, eps, inv_count, lsum, acc);
+        }
+    } else {
+        load_scene(sc_lds, sc);
+        Geom g_next = geometry(K, sc, x, y);
+        for (int s = 0; s < S; ++s) {
+            const Geom g = g_next;
+            load_scene(sc_lds + (s + 1 < S ? s + 1 : s) * 9, sc);
+            g_next = geometry(K, sc, x, y);
+            loss_pixel_scene<NL, WITH_GRAD>(K, g, mi, mt, eps, inv_count, lsum, acc);
+        }
     }
     return lsum;
 }
@@ -690,7 +737,7 @@ __device__ __forceinline__ void head_bwd(const Head &h, const Grad &g, float ge[
 // One thread = one pixel (VEC = 1: the kernel is VALU-bound, wider loads measured no gain
 // and cost occupancy).  WITH_L1 adds SVBRDFL1Loss on the 24 values already in registers.
 template <bool WITH_GRAD, bool WITH_L1, bool HEAD>
-__global__ __launch_bounds__(kLossThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_rendering_loss(const float *__restrict__ input,
+__global__ __launch_bounds__(kLossThreads) __attribute__((amdgpu_waves_per_eu(SVBRDF_K3_MIN_WAVES, 8))) void k_rendering_loss(const float *__restrict__ input,
                                                                  const float *__restrict__ target,
                                                                  const float *__restrict__ scenes,
                                                                  const float *__restrict__ xrow, float eps,
@@ -700,12 +747,17 @@ __global__ __launch_bounds__(kLossThreads) __attribute__((amdgpu_waves_per_eu(4,
                                                                  float *__restrict__ loss_out, int S, int H, int W)
 {
     __shared__ float wave_part[kLossThreads / 64];
+    extern __shared__ __attribute__((aligned(16))) float sc_lds[];      // [S][9] scene scalars of batch item b
     constexpr float kLn2 = 0.693147180559945309417f;
     const size_t plane = (size_t)H * W;
     const size_t pix = (size_t)blockIdx.x * kLossThreads + threadIdx.x;
     const int b = blockIdx.y;
     const bool active = pix < plane;
     float lsum = 0.0f;
+    if (!WITH_GRAD) {    // forward-only kernels stage the scene table of batch item b in LDS (see loss_scene_loop)
+        for (int i = threadIdx.x; i < S * 9; i += kLossThreads) sc_lds[i] = scenes[(size_t)b * S * 9 + i];
+        __syncthreads();
+    }
     if (active) {
         Maps in[1], tg[1];
         Head head;
@@ -745,9 +797,9 @@ __global__ __launch_bounds__(kLossThreads) __attribute__((amdgpu_waves_per_eu(4,
         pixel_coords<1>(xrow, pix, W, x, y);
         const float *__restrict__ scp = scenes + (size_t)b * S * 9;
         if (__all(tied))     // wave-uniform: every lane's input AND target roughness channels are tied
-            lsum = loss_scene_loop<1, WITH_GRAD>(mi, mt, x[0], y, scp, S, eps, inv_count, acc);
+            lsum = loss_scene_loop<1, WITH_GRAD>(mi, mt, x[0], y, scp, sc_lds, S, eps, inv_count, acc);
         else
-            lsum = loss_scene_loop<3, WITH_GRAD>(mi, mt, x[0], y, scp, S, eps, inv_count, acc);
+            lsum = loss_scene_loop<3, WITH_GRAD>(mi, mt, x[0], y, scp, sc_lds, S, eps, inv_count, acc);
         if (WITH_L1) lsum = fma_(l1sum, l1.sum_scale, lsum);
         if (WITH_GRAD) {
             if (HEAD) {
@@ -989,9 +1041,11 @@ static int loss_impl(const char *who, bool head, const float *input, const float
     const double loss_scale = std::ldexp(1.0, -k) / count;
     if ((unsigned long long)grid.x * grid.y >= (1ULL << 16) * kLossSlots)
         return fail(SVBRDF_ERR_DIMS, "loss: too many workgroups for the arrival counters");
+    const size_t lds_bytes = grad_input ? 0 : (size_t)S * 9 * sizeof(float);   // forward-only kernels stage scenes in LDS
+    if (lds_bytes > 60 * 1024) return fail(SVBRDF_ERR_DIMS, "loss: too many scenes per item for the LDS stage (max 1706)");
     const L1Params l1{l1_weight * (float)S, (float)((double)l1_weight / ((double)B * 3.0 * (double)plane)), eps_l1};
 #define SVBRDF_LAUNCH_K3(G, L, HD)                                                                          \
-    hipLaunchKernelGGL((k_rendering_loss<G, L, HD>), grid, block, 0, st, input, target, scenes, xrow, eps,  \
+    hipLaunchKernelGGL((k_rendering_loss<G, L, HD>), grid, block, lds_bytes, st, input, target, scenes, xrow, eps, \
                        inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, S, H, W)
     const int variant = (head ? 4 : 0) | (l1_weight != 0.0f ? 2 : 0) | (grad_input ? 1 : 0);
     switch (variant) {

@@ -16,13 +16,14 @@ __device__ __forceinline__ float isq(float x)
     if (KIND == 0) return x * 0.21f + 0.13f;
     return __builtin_amdgcn_rsqf(x);
 }
-template <int KIND>
+template <int KIND, int UNROLL>
 __global__ __launch_bounds__(256) void k(float *out, int iters, float seed)
 {
     float x = seed + threadIdx.x * 1e-3f, y = seed * 0.5f + blockIdx.x * 1e-4f;
     float n0 = 0.1f + x, n1 = 0.2f - y, n2 = 0.9f, A = 0.3f + x * y, s0 = 0.5f, d0 = 0.4f;
     float acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
     float c0 = seed, c1 = seed * 2, c2 = seed * 3, l0 = -seed, l1 = seed * 0.7f, l2 = seed * 1.5f;
+#pragma unroll UNROLL
     for (int i = 0; i < iters; ++i) {
         float ax = c0 - x, ay = c1 - y, az = c2;
         float bx = l0 - x, by = l1 - y, bz = l2;
@@ -64,15 +65,15 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed)
     }
     if (acc0 + acc1 + acc2 + acc3 == 12345.6f) out[0] = acc0;
 }
-template <int KIND> void run(const char *name, float *d, int bpc, int instr_per_iter)
+template <int KIND, int UNROLL> void run(const char *name, float *d, int bpc, int instr_per_iter)
 {
     const int iters = 4000, blocks = 256 * bpc;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, 10, 1.0f); (void)hipDeviceSynchronize();
-    (void)hipEventRecord(e0); hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0f); (void)hipEventRecord(e1);
+    hipLaunchKernelGGL((k<KIND, UNROLL>), dim3(blocks), dim3(256), 0, 0, d, 10, 1.0f); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0); hipLaunchKernelGGL((k<KIND, UNROLL>), dim3(blocks), dim3(256), 0, 0, d, iters, 1.0f); (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const double per_iter_ns = ms * 1e6 / iters / (bpc);
-    printf("%-10s waves/SIMD=%d  %8.3f ms  %7.1f ns per wave-iteration per SIMD", name, bpc, ms, per_iter_ns);
+    printf("%-24s waves/SIMD=%d  %8.3f ms  %7.1f ns per wave-iteration per SIMD", name, bpc, ms, per_iter_ns);
     if (instr_per_iter) printf("  = %.2f ns/instr (%d VALU/iter)", per_iter_ns / instr_per_iter, instr_per_iter);
     printf("\n");
 }
@@ -80,6 +81,10 @@ int main(int argc, char **argv)
 {
     float *d; (void)hipMalloc(&d, 4);
     const int n0 = argc > 1 ? atoi(argv[1]) : 0, n1 = argc > 2 ? atoi(argv[2]) : 0;
-    for (int bpc : {1, 2, 3, 4, 6, 8}) { run<0>("no-trans", d, bpc, n0); run<1>("with-trans", d, bpc, n1); }
+    for (int bpc : {4, 8}) {
+        run<0, 1>("no-trans", d, bpc, n0); run<1, 1>("with-trans", d, bpc, n1);
+        run<0, 4>("no-trans x4 unrolled", d, bpc, n0); run<1, 4>("with-trans x4 unrolled", d, bpc, n1);
+        run<0, 16>("no-trans x16 unrolled", d, bpc, n0); run<1, 16>("with-trans x16 unrolled", d, bpc, n1);
+    }
     return 0;
 }
