@@ -76,3 +76,26 @@ if ext is not None:
     print("C++ sampler: %.1f us" % T(lambda: ext.sample_scene_table(8, 3, 6))[0])
     print("step via RenderingLoss (ext path): host %.1f us wall %.1f" % T(step))
     os.environ["X"] = "1"
+
+if ext is not None:
+    def split_ext():
+        fw = bw = oth = 0.0
+        raw = _native._raw_stream(dev)
+        for _ in range(300):
+            t0 = time.perf_counter()
+            inp.grad = None
+            t1 = time.perf_counter()
+            l = ext.fused_loss(inp, tgt, 3, 6, 0.1, 0.0, 0.01, raw, False)
+            t2 = time.perf_counter()
+            l.backward()
+            t3 = time.perf_counter()
+            oth += t1 - t0; fw += t2 - t1; bw += t3 - t2
+        torch.cuda.synchronize()
+        print("ext path: grad=None %.1f us, fused_loss() %.1f us (C++ sampler %.1f), backward() %.1f us" % (
+            oth / 300 * 1e6, fw / 300 * 1e6, T(lambda: ext.sample_scene_table(8, 3, 6))[0], bw / 300 * 1e6))
+    split_ext()
+    tds = td
+    def fwd_only():
+        with torch.no_grad():
+            ext.fused_loss_with_scenes(inp.detach(), tgt, tds, 0.1, 0.0, 0.01, _native._raw_stream(dev), False)
+    print("fused_loss_with_scenes, no grad, no sampling: host %.1f us wall %.1f" % T(fwd_only))
