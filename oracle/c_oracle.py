@@ -155,3 +155,16 @@ def head_loss(encoded9, target, scenes, l1_weight=0.1, eps=0.1, eps_l1=0.01, xro
     if rc:
         raise RuntimeError("oracle head_loss rc=%d" % rc)
     return loss.value, grad
+
+
+def loss_tie_map(input, target, scenes, eps=0.1, xrow=None):
+    """[B,H,W] float64: smallest |log difference| over scenes/channels per pixel (see svbrdf_oracle.c)."""
+    input, scenes, B, S, H, W = _dims(input, scenes)
+    target = _f32(target)
+    xrow = make_xrow(W) if xrow is None else _f32(xrow)
+    out = np.empty((B, H, W), dtype=np.float64)
+    rc = lib().svbrdf_oracle_loss_tie_map(_p(input), _p(target), _p(scenes), _p(xrow), ctypes.c_float(eps),
+                                          _p(out, _f64p), B, S, H, W)
+    if rc:
+        raise RuntimeError("oracle loss_tie_map rc=%d" % rc)
+    return out

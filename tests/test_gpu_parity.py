@@ -1,6 +1,7 @@
 """GPU parity tests proper: the HIP kernels, called through the C ABI (ctypes) and through
 the reference-shaped Python interface, against the C oracle and the golden fixtures."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -334,6 +335,28 @@ def test_full_size_properties_config2(dev, native, oracle):
         lo, go = oracle.rendering_loss(inp[b:b + 1], tgt[b:b + 1], table[b:b + 1])
         assert_loss_close(per_item[b], lo, "item %d vs oracle" % b)
         assert_grad_close(_np(grad[b:b + 1]) * B, go, "item %d grad vs oracle" % b)
+
+
+def test_config5_size_512_32_scenes(dev, native, oracle):
+    """BASELINE config 5 shape per GPU item: 512x512 patches, 32 scenes (11 random + 21 specular -- the
+    21-element normal_ draws take torch's vectorised path), mixed loss; full comparison with the oracle"""
+    from svbrdf_estimation_amd import losses, renderers
+    B, H = 2, 512
+    inp, tgt = synth.make_maps(95, B, H), synth.make_maps(96, B, H)
+    fn = losses.MixedLoss(renderers.LocalRenderer())
+    fn.rendering_loss.random_configuration_count, fn.rendering_loss.specular_configuration_count = 11, 21
+    torch.manual_seed(55)
+    table = fn.rendering_loss.sample_scene_table(B).numpy()
+    assert table.shape == (B, 32, 9)
+    x = _t(inp, dev).requires_grad_(True)
+    torch.manual_seed(55)
+    loss = fn(x, _t(tgt, dev))
+    loss.backward()
+    oracle.set_threads(min(32, os.cpu_count() or 1))
+    ref_l, ref_g = oracle.mixed_loss(inp, tgt, table, 0.1)
+    _, g64 = oracle.mixed_loss(inp, tgt, table, 0.1, f64=True)
+    assert_loss_close(loss.item(), ref_l, "config-5 mixed loss")
+    assert_grad_close(_np(x.grad), ref_g, "config-5 gradient", f64=g64, tie_map=oracle.loss_tie_map(inp, tgt, table))
 
 
 # ---------------------------------------------------------------- plugin interface (renderers.py:67)

@@ -59,9 +59,20 @@ def assert_render_vs_reference(a, ref, f64, what="rendering", scale=None):
     assert bad == 0, "%s: %d pixels differ by more than the reference's own rounding error" % (what, bad)
 
 
-def assert_grad_close(a, b, what="gradient", rtol=GRAD_RTOL, afrac=GRAD_ATOL_FRAC, f64=None):
+TIE_LEVEL = 1e-6     # |log a - log b| below this: sign() in the L1 gradient is rounding noise
+
+
+def assert_grad_close(a, b, what="gradient", rtol=GRAD_RTOL, afrac=GRAD_ATOL_FRAC, f64=None, tie_map=None):
+    """tie_map [B,H,W] (oracle.loss_tie_map): pixels where some |log difference| < TIE_LEVEL are excluded --
+    there the sign of that term, hence the gradient, is undetermined in fp32 for the reference too (expected
+    fraction ~ 2e-6 per term and pixel: 6e-5 of the pixels at 32 scenes, measured 31 of 524288); they must stay
+    below 1e-3 of the pixels."""
     extra = None if f64 is None else 2.0 * np.abs(np.asarray(b, np.float64) - np.asarray(f64, np.float64))
     err, tol, scale = _viol(a, b, rtol, afrac, extra=extra)
+    if tie_map is not None:
+        ties = np.asarray(tie_map) < TIE_LEVEL
+        assert ties.mean() < 1e-3 or ties.sum() <= 2, "%s: %d tie pixels" % (what, int(ties.sum()))
+        err = np.where(ties[:, None, :, :], 0.0, err)
     if f64 is not None:    # the widened bound may only be needed for a handful of elements
         strict_ok = float((err <= rtol * np.abs(np.asarray(b, np.float64)) + afrac * scale).mean())
         assert strict_ok >= 0.999, "%s: only %.4f%% of elements within the strict bound" % (what, 100 * strict_ok)
