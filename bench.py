@@ -223,7 +223,7 @@ def main():
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_rendering_loss<true,false> (single launch: both shadings, log/L1, adjoint, loss finalise)",
+                         "kernel": "k_rendering_loss<GRAD=true,L1=false,HEAD=false> (single launch: both shadings, log/L1, adjoint, loss finalise)",
                          "kernel_limited_patches_per_s": B / (kernel_ms_avg * 1e-3),
                          "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
                          "algorithmic_bytes_per_launch": alg_bytes,
