@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -172,9 +173,12 @@ struct State {
     void *ev_begin = nullptr, *ev_end = nullptr;   // measurement aid: raw hipEvent_t pair around the next launch
     Sampler sampler;
     Ring ring;
-    at::Tensor workspace, xrow;      // per process: one device per process (one process per GPU)
-    int64_t xrow_w = -1;
-    int ws_device = -1;
+    // one device per process (one process per GPU); scratch per stream so that calls enqueued on
+    // different streams never share the loss accumulators; xrow per width
+    std::map<int64_t, at::Tensor> workspace_by_stream;
+    std::map<int64_t, at::Tensor> xrow_by_width;
+    at::Tensor workspace, xrow;      // the ones selected for the call in flight (under `mu`)
+    int device = -1;
 } g_state;
 
 // ------------------------------------------------------------------------------------------
@@ -243,23 +247,27 @@ struct FusedLoss : public torch::autograd::Function<FusedLoss> {
     }
 };
 
-void ensure_device_state(const at::Tensor &input, int S)
+void ensure_device_state(const at::Tensor &input, int S, int64_t stream)
 {
     const int B = (int)input.size(0), H = (int)input.size(2), W = (int)input.size(3);
     const int dev = input.device().index();
-    const size_t need = g_abi.ws_bytes(B, S, H, W);
-    if (!g_state.workspace.defined() || g_state.ws_device != dev || (size_t)g_state.workspace.numel() * 8 < need) {
-        g_state.workspace = at::zeros({(int64_t)std::max<size_t>((need + 7) / 8, 8)},
-                                      at::TensorOptions().dtype(at::kLong).device(input.device()));
-        g_state.ws_device = dev;
-        g_state.xrow_w = -1;
+    if (g_state.device != dev) {          // first call, or the process switched devices: drop everything cached
+        g_state.workspace_by_stream.clear();
+        g_state.xrow_by_width.clear();
+        g_state.device = dev;
     }
-    if (g_state.xrow_w != W) {
+    const size_t need = g_abi.ws_bytes(B, S, H, W);
+    auto &ws = g_state.workspace_by_stream[stream];
+    if (!ws.defined() || (size_t)ws.numel() * 8 < need)
+        ws = at::zeros({(int64_t)std::max<size_t>((need + 7) / 8, 8)}, at::TensorOptions().dtype(at::kLong).device(input.device()));
+    g_state.workspace = ws;
+    auto &xr = g_state.xrow_by_width[W];
+    if (!xr.defined()) {
         auto host = at::empty({W}, at::TensorOptions().dtype(at::kFloat));
         check(g_abi.make_xrow(host.data_ptr<float>(), W), "svbrdf_make_xrow");
-        g_state.xrow = host.to(input.device());
-        g_state.xrow_w = W;
+        xr = host.to(input.device());
     }
+    g_state.xrow = xr;
 }
 
 void check_inputs(const at::Tensor &input, const at::Tensor &target, bool head)
@@ -286,7 +294,7 @@ at::Tensor fused_loss(const at::Tensor &input, const at::Tensor &target, int64_t
     if (g_state.sampler.B != B || g_state.sampler.R != n_random || g_state.sampler.M != n_specular)
         g_state.sampler.init(B, n_random, n_specular);
     const auto table = g_state.sampler.sample();
-    ensure_device_state(input, (int)(n_random + n_specular));
+    ensure_device_state(input, (int)(n_random + n_specular), stream);
     const auto scenes = g_state.ring.upload(table, input.device(), reinterpret_cast<void *>(stream));
     return FusedLoss::apply(input, target, scenes, eps, l1_weight, eps_l1, stream, head);
 }
@@ -300,7 +308,7 @@ at::Tensor fused_loss_with_scenes(const at::Tensor &input, const at::Tensor &tar
                     scenes.scalar_type() == at::kFloat,
                 "scenes must be a [B,S,9] fp32 device tensor");
     std::lock_guard<std::mutex> lock(g_state.mu);
-    ensure_device_state(input, (int)scenes.size(1));
+    ensure_device_state(input, (int)scenes.size(1), stream);
     return FusedLoss::apply(input, target, scenes.contiguous(), eps, l1_weight, eps_l1, stream, head);
 }
 
