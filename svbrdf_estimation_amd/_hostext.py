@@ -26,7 +26,7 @@ def build(verbose=False):
     from torch.utils import cpp_extension
     os.makedirs(BUILD_DIR, exist_ok=True)
     src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "host_ext.cpp")
-    cpp_extension.load(name=NAME, sources=[src], build_directory=BUILD_DIR, extra_cflags=["-O2", "-std=c++17"],
+    cpp_extension.load(name=NAME, sources=[src], build_directory=BUILD_DIR, extra_cflags=["-O2", "-std=c++17", "-ffp-contract=off"],
                        extra_ldflags=["-ldl"], verbose=verbose)
     return _SO
 

@@ -78,27 +78,27 @@ void check(int rc, const char *what)
 // (see svbrdf_estimation_amd/environment.py BatchSceneSampler, which this mirrors op for op)
 // ------------------------------------------------------------------------------------------
 struct Sampler {
-    int64_t B = -1, R = -1, M = -1;
-    at::Tensor raw, i1, i2, lo, width, nrm, shift, shift_buf, mirror, col_r, col_s;
+    int64_t B = -1, R = -1, M = -1, D = 0;
+    at::Tensor raw, nrm, shift_buf;                 // RNG targets: [B,4R+2M], [B,2,M], [B,M,2]
+    at::Tensor r1, phi, radius, cosv, sinv, zin, z, dist;   // flat fp32 work buffers of B*D (dist: B*2*M)
     std::vector<at::Tensor> raw_rows, nrm_rows, nrm_v, nrm_l, shift_rows;
+    float lo = 0.0f, width = 0.0f, two_pi = 0.0f, shift_z = 0.0f;
 
     void init(int64_t b, int64_t r, int64_t m)
     {
-        B = b; R = r; M = m;
+        B = b; R = r; M = m; D = 2 * R + M;
         const auto f = at::TensorOptions().dtype(at::kFloat);
         raw = at::empty({B, 4 * R + 2 * M}, f);
-        const auto idx = at::arange(4 * R + 2 * M, at::TensorOptions().dtype(at::kLong));
-        i1 = at::cat({idx.slice(0, 0, R), idx.slice(0, 2 * R, 3 * R), idx.slice(0, 4 * R, 4 * R + M)});
-        i2 = at::cat({idx.slice(0, R, 2 * R), idx.slice(0, 3 * R, 4 * R), idx.slice(0, 4 * R + M, 4 * R + 2 * M)});
-        lo = at::scalar_tensor(0.0 + 0.001, f);
-        width = at::scalar_tensor(1.0 - 0.1, f) - lo;
         nrm = at::empty({B, 2, M}, f);
-        shift = at::empty({B, M, 3}, f);
-        shift.select(2, 2).copy_(at::zeros({B, M}, f) + 0.0001);
         shift_buf = at::empty({B, M, 2}, f);
-        mirror = at::tensor({-1.0f, -1.0f, 1.0f}, f);
-        col_r = at::full({B, R, 3}, 20.0, f);
-        col_s = at::full({B, M, 3}, 50.0, f);
+        for (at::Tensor *t : {&r1, &phi, &radius, &cosv, &sinv, &zin, &z}) *t = at::empty({B * D}, f);
+        dist = at::empty({B, 2, M}, f);
+        // the constants exactly as torch forms them: float32(0.0 + 0.001), float32(1.0 - 0.1) - lo in fp32,
+        // float32(2*pi) (python scalar times fp32 tensor), float32(0.0001) (zeros + 0.0001)
+        lo = (float)(0.0 + 0.001);
+        width = (float)(1.0 - 0.1) - lo;
+        two_pi = (float)(2 * M_PI);
+        shift_z = (float)0.0001;
         raw_rows.clear(); nrm_rows.clear(); nrm_v.clear(); nrm_l.clear(); shift_rows.clear();
         for (int64_t i = 0; i < B; ++i) {
             raw_rows.push_back(raw.select(0, i));
@@ -109,7 +109,18 @@ struct Sampler {
         }
     }
 
+    // Only the RNG draws and the five transcendental maps (sqrt, cos, sin, sqrt, exp -- whose CPU
+    // implementations are torch's/MKL's and cannot be re-stated bit for bit) go through ATen; the
+    // affine steps are plain fp32 loops in the reference's operation order (this file is compiled
+    // with -ffp-contract=off; uniform_(lo,hi) is fma(u, hi-lo, lo) of the raw 24-bit u, verified).
     at::Tensor sample()
+    {
+        auto table = at::empty({B, R + M, 9}, at::TensorOptions().dtype(at::kFloat));
+        sample_into(table.data_ptr<float>());
+        return table;
+    }
+
+    void sample_into(float *t)      // t: B*(R+M)*9 floats (e.g. a pinned upload slot)
     {
         for (int64_t i = 0; i < B; ++i) {
             raw_rows[i].uniform_(0.0, 1.0);
@@ -123,21 +134,50 @@ struct Sampler {
                 shift_rows[i].uniform_(-1.0, 1.0);
             }
         }
-        const auto r1 = at::addcmul(lo, raw.index_select(1, i1), width);   // uniform_(lo,hi) == fma(u, hi-lo, lo)
-        const auto r2 = raw.index_select(1, i2);
-        const auto radius = at::sqrt(r1);
-        const auto phi = r2 * (2 * M_PI);
-        const auto dirs = at::stack({radius * at::cos(phi), radius * at::sin(phi), at::sqrt(1.0 - at::pow(radius, 2))}, -1);
-        std::vector<at::Tensor> parts;
-        if (R > 0) parts.push_back(at::cat({dirs.slice(1, 0, R), dirs.slice(1, R, 2 * R), col_r}, -1));
-        if (M > 0) {
-            const auto view = dirs.slice(1, 2 * R, 2 * R + M);
-            const auto dist = at::exp(nrm).unsqueeze(-1);
-            shift.slice(2, 0, 2).copy_(shift_buf);
-            parts.push_back(at::cat({view * dist.select(1, 0) + shift, (view * mirror) * dist.select(1, 1) + shift, col_s}, -1));
+        const int64_t W = 4 * R + 2 * M;
+        const float *u = raw.data_ptr<float>();
+        float *pr1 = r1.data_ptr<float>(), *pphi = phi.data_ptr<float>();
+        for (int64_t b = 0; b < B; ++b) {
+            const float *row = u + b * W;
+            float *o1 = pr1 + b * D, *o2 = pphi + b * D;
+            for (int64_t j = 0; j < D; ++j) {           // direction j: view_r | light_r | view_s
+                const int64_t i1 = j < R ? j : (j < 2 * R ? 2 * R + (j - R) : 4 * R + (j - 2 * R));
+                const int64_t i2 = j < R ? R + j : (j < 2 * R ? 3 * R + (j - R) : 4 * R + M + (j - 2 * R));
+                o1[j] = std::fmaf(row[i1], width, lo);
+                o2[j] = row[i2] * two_pi;
+            }
         }
-        if (parts.empty()) return at::zeros({B, 0, 9}, at::TensorOptions().dtype(at::kFloat));
-        return parts.size() == 1 ? parts[0] : at::cat(parts, 1);
+        at::sqrt_out(radius, r1);
+        at::cos_out(cosv, phi);
+        at::sin_out(sinv, phi);
+        const float *rad = radius.data_ptr<float>();
+        float *pz = zin.data_ptr<float>();
+        for (int64_t k = 0; k < B * D; ++k) pz[k] = 1.0f - rad[k] * rad[k];
+        at::sqrt_out(z, zin);
+        if (M > 0) at::exp_out(dist, nrm);
+        const float *c = cosv.data_ptr<float>(), *s = sinv.data_ptr<float>(), *zz = z.data_ptr<float>();
+        const float *dd = dist.data_ptr<float>(), *sh = shift_buf.data_ptr<float>();
+        for (int64_t b = 0; b < B; ++b) {
+            float *tb = t + b * (R + M) * 9;
+            const int64_t base = b * D;
+            for (int64_t j = 0; j < R; ++j) {
+                const int64_t v = base + j, l = base + R + j;
+                float *o = tb + j * 9;
+                o[0] = rad[v] * c[v]; o[1] = rad[v] * s[v]; o[2] = zz[v];
+                o[3] = rad[l] * c[l]; o[4] = rad[l] * s[l]; o[5] = zz[l];
+                o[6] = o[7] = o[8] = 20.0f;
+            }
+            for (int64_t m = 0; m < M; ++m) {
+                const int64_t v = base + 2 * R + m;
+                const float vx = rad[v] * c[v], vy = rad[v] * s[v], vz = zz[v];
+                const float dv = dd[(b * 2 + 0) * M + m], dl = dd[(b * 2 + 1) * M + m];
+                const float sx = sh[(b * M + m) * 2 + 0], sy = sh[(b * M + m) * 2 + 1];
+                float *o = tb + (R + m) * 9;
+                o[0] = vx * dv + sx; o[1] = vy * dv + sy; o[2] = vz * dv + shift_z;
+                o[3] = (vx * -1.0f) * dl + sx; o[4] = (vy * -1.0f) * dl + sy; o[5] = (vz * 1.0f) * dl + shift_z;
+                o[6] = o[7] = o[8] = 50.0f;
+            }
+        }
     }
 };
 
@@ -151,19 +191,24 @@ struct Ring {
     bool used[kDepth] = {false};
     int next = 0;
 
-    at::Tensor upload(const at::Tensor &host, const at::Device &device, void *stream)
+    // a pinned [numel] fp32 slot that no pending upload still reads
+    at::Tensor acquire(int64_t numel, int &index)
     {
-        const int i = next;
+        index = next;
         next = (next + 1) % kDepth;
-        if (used[i]) g_abi.ev_sync(event[i]);
-        if (!slot[i].defined() || slot[i].numel() < host.numel())
-            slot[i] = at::empty({std::max<int64_t>(host.numel(), 1024)}, at::TensorOptions().dtype(at::kFloat).pinned_memory(true));
-        auto view = slot[i].slice(0, 0, host.numel()).view(host.sizes());
-        view.copy_(host);
-        auto dev = view.to(device, /*non_blocking=*/true);
-        if (!event[i]) TORCH_CHECK(g_abi.ev_create(&event[i], 0x2 /* hipEventDisableTiming */) == 0, "hipEventCreate failed");
-        TORCH_CHECK(g_abi.ev_record(event[i], stream) == 0, "hipEventRecord failed");
-        used[i] = true;
+        if (used[index]) g_abi.ev_sync(event[index]);
+        if (!slot[index].defined() || slot[index].numel() < numel)
+            slot[index] = at::empty({std::max<int64_t>(numel, 1024)}, at::TensorOptions().dtype(at::kFloat).pinned_memory(true));
+        return slot[index].slice(0, 0, numel);
+    }
+
+    // asynchronous H2D of an acquired slot; the slot is busy until the recorded event completes
+    at::Tensor submit(const at::Tensor &view, int index, at::IntArrayRef shape, const at::Device &device, void *stream)
+    {
+        auto dev = view.view(shape).to(device, /*non_blocking=*/true);
+        if (!event[index]) TORCH_CHECK(g_abi.ev_create(&event[index], 0x2 /* hipEventDisableTiming */) == 0, "hipEventCreate failed");
+        TORCH_CHECK(g_abi.ev_record(event[index], stream) == 0, "hipEventRecord failed");
+        used[index] = true;
         return dev;
     }
 };
@@ -293,9 +338,12 @@ at::Tensor fused_loss(const at::Tensor &input, const at::Tensor &target, int64_t
     const int64_t B = input.size(0);
     if (g_state.sampler.B != B || g_state.sampler.R != n_random || g_state.sampler.M != n_specular)
         g_state.sampler.init(B, n_random, n_specular);
-    const auto table = g_state.sampler.sample();
-    ensure_device_state(input, (int)(n_random + n_specular), stream);
-    const auto scenes = g_state.ring.upload(table, input.device(), reinterpret_cast<void *>(stream));
+    const int64_t S = n_random + n_specular;
+    int slot = 0;
+    auto pinned = g_state.ring.acquire(B * S * 9, slot);
+    g_state.sampler.sample_into(pinned.data_ptr<float>());           // drawn straight into the upload slot
+    ensure_device_state(input, (int)S, stream);
+    const auto scenes = g_state.ring.submit(pinned, slot, {B, S, 9}, input.device(), reinterpret_cast<void *>(stream));
     return FusedLoss::apply(input, target, scenes, eps, l1_weight, eps_l1, stream, head);
 }
 
