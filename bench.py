@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--specular-scenes", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
+    ap.add_argument("--engine-threads", action="store_true",
+                    help="keep PyTorch's multithreaded backward engine (default: run backward on the calling thread; "
+                         "one process drives one GPU, the device-thread hop only adds wake-up latency)")
     return ap.parse_args()
 
 
@@ -176,6 +179,8 @@ def main():
         loss.backward()
         return loss
 
+    if not args.engine_threads:
+        torch.autograd.set_multithreading_enabled(False)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -240,6 +245,7 @@ def main():
                                                    / (FP32_VALU_PEAK_TFLOPS * 1e12)},
             "loss": mean_loss,
             "host_path": "native C++ extension (csrc/host_ext.cpp)" if ext is not None else "python + ctypes",
+            "autograd_engine": "multithreaded" if args.engine_threads else "calling thread",
         }
         if world == 1 and not args.no_cpu_baseline:
             table = loss_fn.sample_scene_table(B)

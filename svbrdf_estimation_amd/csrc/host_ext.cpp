@@ -279,13 +279,17 @@ struct FusedLoss : public torch::autograd::Function<FusedLoss> {
         ctx->saved_data["done"] = true;
         void *st = reinterpret_cast<void *>(ctx->saved_data["stream"].toInt());   // backward runs on the forward's stream
         const auto scale = grad_out[0].detach().to(at::kFloat).reshape({1});
+        // The buffers are MOVED out of the node: AccumulateGrad adopts a gradient it holds the only
+        // reference to and clones it otherwise (measured: a 25 MB device copy, 7.4 us, per step).
         at::Tensor gi, gt;
         if (ctx->saved_data["has_in"].toBool()) {
-            gi = ctx->saved_data["grad_in"].toTensor();
+            gi = std::move(ctx->saved_data["grad_in"]).toTensor();
+            ctx->saved_data.erase("grad_in");
             check(g_abi.scale(gi.data_ptr<float>(), scale.data_ptr<float>(), (size_t)gi.numel(), st), "svbrdf_scale_inplace");
         }
         if (ctx->saved_data["has_tg"].toBool()) {
-            gt = ctx->saved_data["grad_tg"].toTensor();
+            gt = std::move(ctx->saved_data["grad_tg"]).toTensor();
+            ctx->saved_data.erase("grad_tg");
             check(g_abi.scale(gt.data_ptr<float>(), scale.data_ptr<float>(), (size_t)gt.numel(), st), "svbrdf_scale_inplace");
         }
         return {gi, gt, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
