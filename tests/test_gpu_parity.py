@@ -566,3 +566,40 @@ def test_training_harness_single_gpu_loss_decreases(dev, tmp_path):
     args = train.parse_args(["--model", "multi", "--views", "2", "--steps", "3", "--warmup", "1", "--batch", "1",
                              "--workers", "0", "--samples", "2"])
     assert np.isfinite(train.run(args)["loss_last_quarter"])
+
+
+# ---------------------------------------------------------------- streams
+
+def test_non_default_and_concurrent_streams(dev, native, golden):
+    """kernels are enqueued on torch's current stream; calls on different streams use separate loss scratch"""
+    from svbrdf_estimation_amd import _hostext, losses, renderers
+    g = golden("g3_loss_48.npz")
+    d_in, d_tg, d_sc = _t(g["input"], dev), _t(g["target"], dev), _t(g["scenes"], dev)
+    ref_l, ref_g = native.rendering_loss(d_in, d_tg, d_sc)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    outs = {}
+    for rep in range(5):                       # interleave launches on the two streams
+        for name, st in (("a", s1), ("b", s2)):
+            with torch.cuda.stream(st):
+                outs[name] = native.rendering_loss(d_in, d_tg, d_sc)
+    torch.cuda.synchronize()
+    for name in ("a", "b"):
+        assert outs[name][0].item() == ref_l.item() and torch.equal(outs[name][1], ref_g)
+    # module path (native host extension and ctypes) on a side stream, seed-reproducible
+    res = []
+    try:
+        for enabled in (True, False):
+            _hostext.set_enabled(enabled)
+            with torch.cuda.stream(s1):
+                x = d_in.clone().requires_grad_(True)
+                torch.manual_seed(int(g["rng_seed"]))
+                loss = losses.RenderingLoss(renderers.LocalRenderer())(x, d_tg)
+                loss.backward()
+            s1.synchronize()
+            res.append((loss.item(), x.grad.clone()))
+    finally:
+        _hostext.set_enabled(True)
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    # (the scenes are re-sampled on this host: equal to the fixture's table up to the CPU math library)
+    assert_loss_close(res[0][0], ref_l.item(), "side-stream module loss", rtol=2e-6)
