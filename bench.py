@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--random-scenes", type=int, default=3)
     ap.add_argument("--specular-scenes", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the K1/K2 stand-alone rates (N=1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     ap.add_argument("--engine-threads", action="store_true",
                     help="keep PyTorch's multithreaded backward engine (default: run backward on the calling thread; "
@@ -115,6 +116,35 @@ def cpu_baseline(args, inp, tgt, table):
     except Exception as e:  # pragma: no cover
         res["c_oracle_error"] = repr(e)
     return res
+
+
+def secondary_kernels(dev, H):
+    """K1 / K2 alone at one render per map with a working set far beyond the 256 MiB Infinity Cache
+    (288 renders: 1.1 GB / 2.0 GB per launch): the HBM-bound kernels of the engine, for the record."""
+    from svbrdf_estimation_amd import _native, environment
+    B = 288
+    gen = torch.Generator().manual_seed(7)
+    maps = synthetic_maps(gen, B, H).to(dev)
+    torch.manual_seed(7)
+    table = environment.BatchSceneSampler(B, 1, 0).sample().to(dev)
+    cot = torch.randn(B, 1, 3, H, H, device=dev)
+    out = {}
+    for name, fn, nbytes in (("K1_render_fwd", lambda: _native.render_fwd(maps, table), 60.0 * H * H * B),
+                             ("K2_render_bwd", lambda: _native.render_bwd(maps, table, cot), 108.0 * H * H * B)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        ms = a.elapsed_time(b) / 10
+        gbps = nbytes / (ms * 1e-3) / 1e9
+        out[name] = {"renders_per_launch": B, "ms_per_launch": ms, "algorithmic_GBps": gbps,
+                     "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "renders_per_s": B / (ms * 1e-3)}
+    return out
 
 
 def main():
@@ -236,6 +266,7 @@ def main():
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac_of_measured_copy_peak": achieved / 6290.0,   # MI355X_MICROARCH.md: float4 copy
                          "kernel": "k_rendering_loss<GRAD=true,L1=false,HEAD=false> (single launch: both shadings, log/L1, adjoint, loss finalise)",
                          "kernel_limited_patches_per_s": B / (kernel_ms_avg * 1e-3),
                          "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
@@ -247,6 +278,8 @@ def main():
             "host_path": "native C++ extension (csrc/host_ext.cpp)" if ext is not None else "python + ctypes",
             "autograd_engine": "multithreaded" if args.engine_threads else "calling thread",
         }
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_kernels(dev, H)
         if world == 1 and not args.no_cpu_baseline:
             table = loss_fn.sample_scene_table(B)
             out["cpu_baseline"] = cpu_baseline(args, inp_h, tgt_h, table)
