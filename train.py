@@ -53,6 +53,10 @@ def parse_args(argv=None):
     ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"))
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl on cuda, gloo on cpu)")
     ap.add_argument("--save", default=None, help="write a checkpoint (model + optimizer state) here at the end")
+    ap.add_argument("--autotune", action="store_true",
+                    help="let MIOpen pick the fastest convolution algorithms (cudnn.benchmark) instead of the "
+                         "reference's deterministic setting (utils.py:11-12)")
+    ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights for the U-Net")
     return ap.parse_args(argv)
 
 
@@ -85,7 +89,12 @@ def run(args):
     else:
         net = models.SingleViewModel(use_coords=not args.no_coords, decode=decode)
     # identical initial weights on every rank: DDP broadcasts rank 0's parameters at construction
+    if args.autotune:
+        torch.backends.cudnn.deterministic = False
+        torch.backends.cudnn.benchmark = True
     net = net.to(dev).train()
+    if args.channels_last:
+        net = net.to(memory_format=torch.channels_last)
     model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank] if on_gpu else None) \
         if world > 1 else net
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
