@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SVBRDF_ABI_VERSION 1
+#define SVBRDF_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define SVBRDF_API __attribute__((visibility("default")))
@@ -117,6 +117,31 @@ SVBRDF_API int svbrdf_head_loss_fwd_bwd(const float *encoded9, const float *targ
                                         const float *xrow, float eps_render, float l1_weight, float eps_l1,
                                         float *loss_out, float *grad_encoded9, void *workspace,
                                         size_t workspace_bytes, int B, int S, int H, int W, void *stream);
+
+/* Scene table handed over in HOST memory.  The reference draws the table on the CPU for every
+ * call (losses.py:35 -> environment.py:18-55), so the caller of this path always holds it in
+ * host memory first.  These two entry points take it there: the B*S rows are copied into the
+ * kernel-argument block of the launch (consumed before the call returns: `scenes_host` may be
+ * reused or freed immediately), so the call enqueues ONE kernel dispatch and nothing else -- no
+ * device buffer for the table, no H2D copy command, no pinned staging.  Limit:
+ * B*S <= SVBRDF_HOST_SCENES_MAX_ROWS (the argument block is 4 KB); larger tables return
+ * SVBRDF_ERR_DIMS and go through the device-pointer entry points above.  Everything else
+ * (results, scratch, stream semantics) is identical to svbrdf_mixed_loss_fwd_bwd /
+ * svbrdf_head_loss_fwd_bwd; l1_weight = 0 gives the plain RenderingLoss. */
+#define SVBRDF_HOST_SCENES_MAX_ROWS 96
+SVBRDF_API int svbrdf_host_scenes_max_rows(void);
+SVBRDF_API int svbrdf_mixed_loss_fwd_bwd_host_scenes(const float *input, const float *target,
+                                                     const float *scenes_host, const float *xrow,
+                                                     float eps_render, float l1_weight, float eps_l1,
+                                                     float *loss_out, float *grad_input, void *workspace,
+                                                     size_t workspace_bytes, int B, int S, int H, int W,
+                                                     void *stream);
+SVBRDF_API int svbrdf_head_loss_fwd_bwd_host_scenes(const float *encoded9, const float *target,
+                                                    const float *scenes_host, const float *xrow,
+                                                    float eps_render, float l1_weight, float eps_l1,
+                                                    float *loss_out, float *grad_encoded9, void *workspace,
+                                                    size_t workspace_bytes, int B, int S, int H, int W,
+                                                    void *stream);
 
 /* data[i] *= scale_dev[0] for i < n, on the device and without a host sync; when the
  * scalar is exactly 1.0 the kernel exits without touching `data`.  Used by the autograd

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SVBRDF_HIP_LIB: load another build of the same ABI (ablation/experiment builds of tools/); default in-tree
 _SO = os.environ.get("SVBRDF_HIP_LIB") or os.path.join(_HERE, "lib", "libsvbrdf_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lock = threading.Lock()
 _lib = None
@@ -75,6 +75,10 @@ def _load():
         lib.svbrdf_mixed_loss_fwd_bwd.restype = ctypes.c_int
         lib.svbrdf_head_loss_fwd_bwd.argtypes = lib.svbrdf_mixed_loss_fwd_bwd.argtypes
         lib.svbrdf_head_loss_fwd_bwd.restype = ctypes.c_int
+        for name in ("svbrdf_mixed_loss_fwd_bwd_host_scenes", "svbrdf_head_loss_fwd_bwd_host_scenes"):
+            getattr(lib, name).argtypes = lib.svbrdf_mixed_loss_fwd_bwd.argtypes
+            getattr(lib, name).restype = ctypes.c_int
+        lib.svbrdf_host_scenes_max_rows.restype = ctypes.c_int
         lib.svbrdf_scale_inplace.argtypes = [_fp, _fp, ctypes.c_size_t, _fp]
         lib.svbrdf_scale_inplace.restype = ctypes.c_int
         for name in ("svbrdf_make_xrow", "svbrdf_render_fwd", "svbrdf_render_bwd", "svbrdf_rendering_loss_fwd_bwd"):
@@ -201,14 +205,22 @@ def rendering_loss(input, target, scenes, eps=0.1, want_grad=True, l1_weight=0.0
     network head is decoded in the kernel.  Returns (loss [1] device tensor, grad or None)."""
     _require_device_f32(input, "input")
     _require_device_f32(target, "target")
-    _require_device_f32(scenes, "scenes")
+    # a HOST table of at most host_scenes_max_rows() rows rides in the kernel-argument block (no upload)
+    host_scenes = isinstance(scenes, torch.Tensor) and not scenes.is_cuda
+    if host_scenes:
+        if scenes.dtype != torch.float32:
+            raise TypeError("scenes must be float32 (got %s)" % scenes.dtype)
+        if scenes.dim() == 3 and scenes.shape[0] * scenes.shape[1] > host_scenes_max_rows():
+            scenes, host_scenes = upload_scene_table(scenes, input.device), False
+    else:
+        _require_device_f32(scenes, "scenes")
     if head:
         if input.dim() != 4 or input.shape[1] != 9 or (input.shape[0],) + tuple(input.shape[2:]) != \
                 (target.shape[0],) + tuple(target.shape[2:]):
             raise ValueError("head=True needs input [B,9,H,W] and target [B,12,H,W]")
     elif input.shape != target.shape:
         raise ValueError("input and target shapes differ: %s vs %s" % (tuple(input.shape), tuple(target.shape)))
-    if target.device != input.device or scenes.device != input.device:
+    if target.device != input.device or (not host_scenes and scenes.device != input.device):
         raise ValueError("input, target and scenes must be on the same device")
     input, target, scenes = input.contiguous(), target.contiguous(), scenes.contiguous()
     B, S, H, W = _dims(target, scenes)
@@ -222,28 +234,42 @@ def rendering_loss(input, target, scenes, eps=0.1, want_grad=True, l1_weight=0.0
     with _on_device(input.device):
         if hook is not None:
             hook("begin")
-        if head:
+        if host_scenes:
+            entry = "svbrdf_head_loss_fwd_bwd_host_scenes" if head else "svbrdf_mixed_loss_fwd_bwd_host_scenes"
+            rc = getattr(lib, entry)(
+                input.data_ptr(), target.data_ptr(), scenes.data_ptr(), xr.data_ptr(),
+                ctypes.c_float(eps), ctypes.c_float(l1_weight), ctypes.c_float(eps_l1), loss.data_ptr(),
+                grad.data_ptr() if want_grad else None, ws.data_ptr(), ws.numel() * 8, B, S, H, W,
+                _stream(input.device))
+        elif head:
+            entry = "svbrdf_head_loss_fwd_bwd"
             rc = lib.svbrdf_head_loss_fwd_bwd(
                 input.data_ptr(), target.data_ptr(), scenes.data_ptr(), xr.data_ptr(),
                 ctypes.c_float(eps), ctypes.c_float(l1_weight), ctypes.c_float(eps_l1), loss.data_ptr(),
                 grad.data_ptr() if want_grad else None, ws.data_ptr(), ws.numel() * 8, B, S, H, W,
                 _stream(input.device))
         elif l1_weight != 0.0:
+            entry = "svbrdf_mixed_loss_fwd_bwd"
             rc = lib.svbrdf_mixed_loss_fwd_bwd(
                 input.data_ptr(), target.data_ptr(), scenes.data_ptr(), xr.data_ptr(),
                 ctypes.c_float(eps), ctypes.c_float(l1_weight), ctypes.c_float(eps_l1), loss.data_ptr(),
                 grad.data_ptr() if want_grad else None, ws.data_ptr(), ws.numel() * 8, B, S, H, W,
                 _stream(input.device))
         else:
+            entry = "svbrdf_rendering_loss_fwd_bwd"
             rc = lib.svbrdf_rendering_loss_fwd_bwd(
                 input.data_ptr(), target.data_ptr(), scenes.data_ptr(), xr.data_ptr(),
                 ctypes.c_float(eps), loss.data_ptr(), grad.data_ptr() if want_grad else None,
                 ws.data_ptr(), ws.numel() * 8, B, S, H, W, _stream(input.device))
         if hook is not None:
             hook("end")
-    _check(rc, "svbrdf_head_loss_fwd_bwd" if head else
-           ("svbrdf_mixed_loss_fwd_bwd" if l1_weight != 0.0 else "svbrdf_rendering_loss_fwd_bwd"))
+    _check(rc, entry)
     return loss, grad
+
+
+def host_scenes_max_rows():
+    """largest B*S the *_host_scenes entry points take (the table rides in the 4 KB kernel-argument block)"""
+    return int(_load().svbrdf_host_scenes_max_rows())
 
 
 def scale_inplace_(data, scale):

@@ -37,6 +37,8 @@ using ev_sync_t = int (*)(void *);
 struct Abi {
     loss_fn_t mixed = nullptr;
     loss_fn_t head = nullptr;     // same signature, input = [B,9,H,W] encoded head output
+    loss_fn_t mixed_host = nullptr, head_host = nullptr;   // scene table in host memory (kernel-argument block)
+    int host_rows = 0;            // largest B*S those two take
     scale_fn_t scale = nullptr;
     ws_fn_t ws_bytes = nullptr;
     err_fn_t last_error = nullptr;
@@ -57,6 +59,9 @@ void bind(const std::string &path)
     };
     g_abi.mixed = reinterpret_cast<loss_fn_t>(need("svbrdf_mixed_loss_fwd_bwd"));
     g_abi.head = reinterpret_cast<loss_fn_t>(need("svbrdf_head_loss_fwd_bwd"));
+    g_abi.mixed_host = reinterpret_cast<loss_fn_t>(need("svbrdf_mixed_loss_fwd_bwd_host_scenes"));
+    g_abi.head_host = reinterpret_cast<loss_fn_t>(need("svbrdf_head_loss_fwd_bwd_host_scenes"));
+    g_abi.host_rows = reinterpret_cast<int (*)()>(need("svbrdf_host_scenes_max_rows"))();
     g_abi.scale = reinterpret_cast<scale_fn_t>(need("svbrdf_scale_inplace"));
     g_abi.ws_bytes = reinterpret_cast<ws_fn_t>(need("svbrdf_rendering_loss_workspace_bytes"));
     g_abi.last_error = reinterpret_cast<err_fn_t>(need("svbrdf_last_error"));
@@ -223,6 +228,7 @@ struct State {
     std::map<int64_t, at::Tensor> workspace_by_stream;
     std::map<int64_t, at::Tensor> xrow_by_width;
     at::Tensor workspace, xrow;      // the ones selected for the call in flight (under `mu`)
+    at::Tensor host_table;           // [B,S,9] sampler target of the by-value route (consumed inside the call)
     int device = -1;
 } g_state;
 
@@ -236,7 +242,10 @@ struct FusedLoss : public torch::autograd::Function<FusedLoss> {
     {
         const bool need_in = input.requires_grad(), need_tg = target.requires_grad();
         TORCH_CHECK(!(head && need_tg), "the head-fused loss has no gradient w.r.t. the target maps");
-        const loss_fn_t kernel = head ? g_abi.head : g_abi.mixed;
+        // a host table goes into the kernel-argument block of the launch, a device table is read in place
+        const bool host_table = scenes.is_cpu();
+        const loss_fn_t kernel = host_table ? (head ? g_abi.head_host : g_abi.mixed_host) : (head ? g_abi.head : g_abi.mixed);
+        const loss_fn_t kernel_tg = host_table ? g_abi.mixed_host : g_abi.mixed;
         const auto in = input.contiguous(), tg = target.contiguous();
         const int B = (int)in.size(0), S = (int)scenes.size(1), H = (int)in.size(2), W = (int)in.size(3);
         auto loss = at::empty({1}, in.options());
@@ -255,7 +264,7 @@ struct FusedLoss : public torch::autograd::Function<FusedLoss> {
         if (need_tg) {   // every term is |g(a) - g(b)|: the target's gradient is the same kernel, roles swapped
             grad_tg = at::empty_like(tg);
             auto loss2 = at::empty({1}, in.options());
-            check(g_abi.mixed(tg.data_ptr<float>(), in.data_ptr<float>(), scenes.data_ptr<float>(),
+            check(kernel_tg(tg.data_ptr<float>(), in.data_ptr<float>(), scenes.data_ptr<float>(),
                               g_state.xrow.data_ptr<float>(), (float)eps, (float)l1_weight, (float)eps_l1,
                               loss2.data_ptr<float>(), grad_tg.data_ptr<float>(), g_state.workspace.data_ptr(),
                               ws_bytes, B, S, H, W, st),
@@ -343,22 +352,32 @@ at::Tensor fused_loss(const at::Tensor &input, const at::Tensor &target, int64_t
     if (g_state.sampler.B != B || g_state.sampler.R != n_random || g_state.sampler.M != n_specular)
         g_state.sampler.init(B, n_random, n_specular);
     const int64_t S = n_random + n_specular;
+    ensure_device_state(input, (int)S, stream);
+    if (B * S <= g_abi.host_rows) {
+        // small table (every reference configuration with B*S <= 96): drawn into a host buffer and handed to the
+        // launch by value -- the step is ONE dispatch, no H2D command, no device buffer, no pinned slot
+        if (!g_state.host_table.defined() || g_state.host_table.size(0) != B || g_state.host_table.size(1) != S)
+            g_state.host_table = at::empty({B, S, 9}, at::TensorOptions().dtype(at::kFloat));
+        g_state.sampler.sample_into(g_state.host_table.data_ptr<float>());
+        return FusedLoss::apply(input, target, g_state.host_table, eps, l1_weight, eps_l1, stream, head);
+    }
     int slot = 0;
     auto pinned = g_state.ring.acquire(B * S * 9, slot);
     g_state.sampler.sample_into(pinned.data_ptr<float>());           // drawn straight into the upload slot
-    ensure_device_state(input, (int)S, stream);
     const auto scenes = g_state.ring.submit(pinned, slot, {B, S, 9}, input.device(), reinterpret_cast<void *>(stream));
     return FusedLoss::apply(input, target, scenes, eps, l1_weight, eps_l1, stream, head);
 }
 
-// same with caller-provided scenes ([B,S,9] on the device)
+// same with caller-provided scenes ([B,S,9] on the device, or on the host if B*S <= svbrdf_host_scenes_max_rows())
 at::Tensor fused_loss_with_scenes(const at::Tensor &input, const at::Tensor &target, const at::Tensor &scenes, double eps,
                                   double l1_weight, double eps_l1, int64_t stream, bool head)
 {
     check_inputs(input, target, head);
-    TORCH_CHECK(scenes.dim() == 3 && scenes.size(0) == input.size(0) && scenes.size(2) == 9 && scenes.is_cuda() &&
+    TORCH_CHECK(scenes.dim() == 3 && scenes.size(0) == input.size(0) && scenes.size(2) == 9 &&
                     scenes.scalar_type() == at::kFloat,
-                "scenes must be a [B,S,9] fp32 device tensor");
+                "scenes must be a [B,S,9] fp32 tensor");
+    TORCH_CHECK(scenes.is_cuda() || scenes.size(0) * scenes.size(1) <= g_abi.host_rows,
+                "a host scene table may hold at most ", g_abi.host_rows, " rows; upload larger ones first");
     std::lock_guard<std::mutex> lock(g_state.mu);
     ensure_device_state(input, (int)scenes.size(1), stream);
     return FusedLoss::apply(input, target, scenes.contiguous(), eps, l1_weight, eps_l1, stream, head);

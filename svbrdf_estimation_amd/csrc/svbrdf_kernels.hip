@@ -6,7 +6,7 @@
 //   K2 render_bwd            the autograd graph of render()        (66 nodes, ~336 ATen calls)
 //   K3 rendering_loss        RenderingLoss.forward + its backward  losses.py:29-52
 //
-// Build:  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared   (csrc/Makefile)
+// Build:  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -shared   (csrc/Makefile)
 //
 // Numerics contract.  The GGX denominator NH^2*(a^2 + (1-NH^2)/NH^2) (renderers.py:26)
 // amplifies a 1-ULP change of NH by 1e3..1e4 next to a highlight, so everything on the path
@@ -17,11 +17,13 @@
 // computation is well conditioned.
 //
 // Data layout.  Maps stay in the reference's BCHW planar layout (W contiguous): lane l of a
-// wave owns VEC horizontally adjacent pixels, so each of the 12 planes is read with one
-// fully coalesced global_load_dword{,x2,x4} per wave (64*VEC*4 contiguous bytes).  The nine
-// scene scalars of a render are uniform per workgroup (a workgroup never straddles batch
-// items) and are fetched with scalar loads into SGPRs; all 3-vector math is intra-lane.
-// No MFMA: the path is elementwise.
+// wave owns VEC horizontally adjacent pixels (K1/K2: VEC in {1,2,4}; K3: one pixel), so each
+// of the 12 planes is read with one fully coalesced global_load_dword{,x2,x4} per wave
+// (64*VEC*4 contiguous bytes).  The nine scene scalars of a render are uniform per workgroup
+// (a workgroup never straddles batch items): K1/K2 read them with scalar loads, K3 keeps the
+// row of the render in flight in VGPRs (an SGPR operand costs 1.75x on a VALU-bound kernel,
+// tools/valu_bank.hip) and stages the table in LDS for the forward-only variants.  All
+// 3-vector math is intra-lane.  No MFMA: the path is elementwise.
 
 #include <hip/hip_runtime.h>
 
@@ -29,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <cstring>
 
 #include "svbrdf_hip.h"
 
@@ -743,14 +746,12 @@ __device__ __forceinline__ void head_bwd(const Head &h, const Grad &g, float ge[
 // One thread = one pixel (VEC = 1: the kernel is VALU-bound, wider loads measured no gain
 // and cost occupancy).  WITH_L1 adds SVBRDFL1Loss on the 24 values already in registers.
 template <bool WITH_GRAD, bool WITH_L1, bool HEAD>
-__global__ __launch_bounds__(kLossThreads) __attribute__((amdgpu_waves_per_eu(SVBRDF_K3_MIN_WAVES, 8))) void k_rendering_loss(const float *__restrict__ input,
-                                                                 const float *__restrict__ target,
-                                                                 const float *__restrict__ scenes,
-                                                                 const float *__restrict__ xrow, float eps,
-                                                                 float inv_count, double loss_scale, float fixed_scale,
-                                                                 L1Params l1, float *__restrict__ grad_input,
-                                                                 unsigned long long *__restrict__ ws,
-                                                                 float *__restrict__ loss_out, int S, int H, int W)
+__device__ __forceinline__ void rendering_loss_body(const float *__restrict__ input, const float *__restrict__ target,
+                                                    const float *__restrict__ scenes, const float *__restrict__ xrow,
+                                                    float eps, float inv_count, double loss_scale, float fixed_scale,
+                                                    L1Params l1, float *__restrict__ grad_input,
+                                                    unsigned long long *__restrict__ ws, float *__restrict__ loss_out,
+                                                    int S, int H, int W)
 {
     __shared__ float wave_part[kLossThreads / 64];
     extern __shared__ __attribute__((aligned(16))) float sc_lds[];      // [S][9] scene scalars of batch item b
@@ -855,6 +856,49 @@ __global__ __launch_bounds__(kLossThreads) __attribute__((amdgpu_waves_per_eu(SV
             loss_out[0] = (float)((double)v * loss_scale);
         }
     }
+}
+
+#define SVBRDF_K3_ATTRS __launch_bounds__(kLossThreads) __attribute__((amdgpu_waves_per_eu(SVBRDF_K3_MIN_WAVES, 8)))
+
+// scene table in device memory (any B*S)
+template <bool WITH_GRAD, bool WITH_L1, bool HEAD>
+__global__ SVBRDF_K3_ATTRS void k_rendering_loss(const float *__restrict__ input, const float *__restrict__ target,
+                                                 const float *__restrict__ scenes, const float *__restrict__ xrow,
+                                                 float eps, float inv_count, double loss_scale, float fixed_scale,
+                                                 L1Params l1, float *__restrict__ grad_input,
+                                                 unsigned long long *__restrict__ ws, float *__restrict__ loss_out,
+                                                 int S, int H, int W)
+{
+    rendering_loss_body<WITH_GRAD, WITH_L1, HEAD>(input, target, scenes, xrow, eps, inv_count, loss_scale, fixed_scale,
+                                                  l1, grad_input, ws, loss_out, S, H, W);
+}
+
+// Scene table passed BY VALUE in the kernel-argument block (B*S <= SVBRDF_HOST_SCENES_MAX_ROWS).
+// The table is drawn on the host for every call (losses.py:35), so it has to cross to the device
+// once per call either way; as a kernel argument it rides in the dispatch packet's own argument
+// buffer: no device allocation, no hipMemcpyAsync command in front of the kernel, no pinned
+// staging slot and no event to guard its reuse.  Measured on config 2: the memcpy route costs
+// ~24 us of host time per call and makes the step host-bound at ~60 us; this route leaves one
+// dispatch per step and the loop GPU-bound at the kernel's own ~53 us.  The body reads the rows
+// with the same wave-uniform scalar loads, from the kernarg segment instead of a global buffer.
+struct SceneBlock {
+    float v[SVBRDF_HOST_SCENES_MAX_ROWS * 9];
+};
+
+// `table` is the FIRST argument, i.e. it sits at offset 0 of the kernarg segment, and is read through
+// the segment pointer: taking the address of the by-value parameter itself makes the compiler
+// copy all 3456 bytes into scratch in the adjoint variants (seen in the resource report).
+template <bool WITH_GRAD, bool WITH_L1, bool HEAD>
+__global__ SVBRDF_K3_ATTRS void k_rendering_loss_inl([[maybe_unused]] const SceneBlock table,
+                                                     const float *__restrict__ input, const float *__restrict__ target,
+                                                     const float *__restrict__ xrow, float eps, float inv_count,
+                                                     double loss_scale, float fixed_scale, L1Params l1,
+                                                     float *__restrict__ grad_input, unsigned long long *__restrict__ ws,
+                                                     float *__restrict__ loss_out, int S, int H, int W)
+{
+    const float *__restrict__ rows = (const float *)__builtin_amdgcn_kernarg_segment_ptr();
+    rendering_loss_body<WITH_GRAD, WITH_L1, HEAD>(input, target, rows, xrow, eps, inv_count, loss_scale, fixed_scale,
+                                                  l1, grad_input, ws, loss_out, S, H, W);
 }
 
 // data[i] *= *scale, skipped entirely (no memory traffic) when *scale == 1: lets the autograd
@@ -1018,13 +1062,15 @@ size_t svbrdf_rendering_loss_workspace_bytes(int B, int S, int H, int W)
     return (kLossSlots + 1) * sizeof(unsigned long long);   // sharded fixed-point accumulators + ticket
 }
 
-static int loss_impl(const char *who, bool head, const float *input, const float *target, const float *scenes,
-                     const float *xrow, float eps, float l1_weight, float eps_l1, float *loss_out,
-                     float *grad_input, void *workspace, size_t workspace_bytes, int B, int S, int H, int W,
-                     void *stream)
+static int loss_impl(const char *who, bool head, bool scenes_on_host, const float *input, const float *target,
+                     const float *scenes, const float *xrow, float eps, float l1_weight, float eps_l1,
+                     float *loss_out, float *grad_input, void *workspace, size_t workspace_bytes, int B, int S,
+                     int H, int W, void *stream)
 {
     if (!input || !target || !scenes || !xrow || !loss_out || !workspace) return fail(SVBRDF_ERR_NULL, who);
     if (int e = check_dims(B, S, H, W)) return e;
+    if (scenes_on_host && (long long)B * S > SVBRDF_HOST_SCENES_MAX_ROWS)
+        return fail(SVBRDF_ERR_DIMS, "host_scenes: B*S exceeds SVBRDF_HOST_SCENES_MAX_ROWS (upload the table and use the device-pointer entry)");
     if (!aligned(input, 4) || !aligned(target, 4) || !aligned(scenes, 4) || !aligned(xrow, 4) ||
         !aligned(loss_out, 4) || !aligned(workspace, 8) || (grad_input && !aligned(grad_input, 4)))
         return fail(SVBRDF_ERR_ALIGN, "loss: pointers must be 4-byte aligned (workspace 8-byte)");
@@ -1050,9 +1096,19 @@ static int loss_impl(const char *who, bool head, const float *input, const float
     const size_t lds_bytes = grad_input ? 0 : (size_t)S * 9 * sizeof(float);   // forward-only kernels stage scenes in LDS
     if (lds_bytes > 60 * 1024) return fail(SVBRDF_ERR_DIMS, "loss: too many scenes per item for the LDS stage (max 1706)");
     const L1Params l1{l1_weight * (float)S, (float)((double)l1_weight / ((double)B * 3.0 * (double)plane)), eps_l1};
-#define SVBRDF_LAUNCH_K3(G, L, HD)                                                                          \
-    hipLaunchKernelGGL((k_rendering_loss<G, L, HD>), grid, block, lds_bytes, st, input, target, scenes, xrow, eps, \
-                       inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, S, H, W)
+    SceneBlock block_arg;      // only the first B*S rows are ever read
+    if (scenes_on_host) std::memcpy(block_arg.v, scenes, (size_t)B * S * 9 * sizeof(float));
+#define SVBRDF_LAUNCH_K3(G, L, HD)                                                                              \
+    do {                                                                                                        \
+        if (scenes_on_host)                                                                                     \
+            hipLaunchKernelGGL((k_rendering_loss_inl<G, L, HD>), grid, block, lds_bytes, st, block_arg, input,   \
+                               target, xrow, eps, inv_count, loss_scale, fixed_scale, l1, grad_input, ws,       \
+                               loss_out, S, H, W);                                                              \
+        else                                                                                                    \
+            hipLaunchKernelGGL((k_rendering_loss<G, L, HD>), grid, block, lds_bytes, st, input, target, scenes, \
+                               xrow, eps, inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, S,  \
+                               H, W);                                                                           \
+    } while (0)
     const int variant = (head ? 4 : 0) | (l1_weight != 0.0f ? 2 : 0) | (grad_input ? 1 : 0);
     switch (variant) {
     case 0: SVBRDF_LAUNCH_K3(false, false, false); break;
@@ -1073,7 +1129,7 @@ int svbrdf_rendering_loss_fwd_bwd(const float *input, const float *target, const
                                   void *workspace, size_t workspace_bytes, int B, int S, int H, int W,
                                   void *stream)
 {
-    return loss_impl("rendering_loss", false, input, target, scenes, xrow, eps, 0.0f, 0.01f, loss_out, grad_input,
+    return loss_impl("rendering_loss", false, false, input, target, scenes, xrow, eps, 0.0f, 0.01f, loss_out, grad_input,
                      workspace, workspace_bytes, B, S, H, W, stream);
 }
 
@@ -1082,7 +1138,7 @@ int svbrdf_mixed_loss_fwd_bwd(const float *input, const float *target, const flo
                               float *grad_input, void *workspace, size_t workspace_bytes, int B, int S, int H,
                               int W, void *stream)
 {
-    return loss_impl("mixed_loss", false, input, target, scenes, xrow, eps_render, l1_weight, eps_l1, loss_out,
+    return loss_impl("mixed_loss", false, false, input, target, scenes, xrow, eps_render, l1_weight, eps_l1, loss_out,
                      grad_input, workspace, workspace_bytes, B, S, H, W, stream);
 }
 
@@ -1090,8 +1146,28 @@ int svbrdf_head_loss_fwd_bwd(const float *encoded9, const float *target, const f
                              float eps_render, float l1_weight, float eps_l1, float *loss_out, float *grad_encoded9,
                              void *workspace, size_t workspace_bytes, int B, int S, int H, int W, void *stream)
 {
-    return loss_impl("head_loss", true, encoded9, target, scenes, xrow, eps_render, l1_weight, eps_l1, loss_out,
+    return loss_impl("head_loss", true, false, encoded9, target, scenes, xrow, eps_render, l1_weight, eps_l1, loss_out,
                      grad_encoded9, workspace, workspace_bytes, B, S, H, W, stream);
+}
+
+int svbrdf_host_scenes_max_rows(void) { return SVBRDF_HOST_SCENES_MAX_ROWS; }
+
+int svbrdf_mixed_loss_fwd_bwd_host_scenes(const float *input, const float *target, const float *scenes_host,
+                                          const float *xrow, float eps_render, float l1_weight, float eps_l1,
+                                          float *loss_out, float *grad_input, void *workspace, size_t workspace_bytes,
+                                          int B, int S, int H, int W, void *stream)
+{
+    return loss_impl("mixed_loss_host_scenes", false, true, input, target, scenes_host, xrow, eps_render, l1_weight,
+                     eps_l1, loss_out, grad_input, workspace, workspace_bytes, B, S, H, W, stream);
+}
+
+int svbrdf_head_loss_fwd_bwd_host_scenes(const float *encoded9, const float *target, const float *scenes_host,
+                                         const float *xrow, float eps_render, float l1_weight, float eps_l1,
+                                         float *loss_out, float *grad_encoded9, void *workspace, size_t workspace_bytes,
+                                         int B, int S, int H, int W, void *stream)
+{
+    return loss_impl("head_loss_host_scenes", true, true, encoded9, target, scenes_host, xrow, eps_render, l1_weight,
+                     eps_l1, loss_out, grad_encoded9, workspace, workspace_bytes, B, S, H, W, stream);
 }
 
 int svbrdf_scale_inplace(float *data, const float *scale_dev, size_t n, void *stream)

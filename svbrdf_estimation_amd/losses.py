@@ -112,7 +112,10 @@ class RenderingLoss(nn.Module):
             raise _native.NativeLibraryError(
                 "RenderingLoss with the MI355X LocalRenderer needs tensors on a ROCm device "
                 "(got %s); there is no CPU fallback" % input.device)
-        return _FusedRenderingLoss.apply(input, target, _native.upload_scene_table(table, input.device),
+        # a small table rides in the kernel-argument block of the launch, a large one is uploaded (pinned ring)
+        if table.shape[0] * table.shape[1] > _native.host_scenes_max_rows():
+            table = _native.upload_scene_table(table, input.device)
+        return _FusedRenderingLoss.apply(input, target, table,
                                          self.epsilon_render, float(l1_weight), float(eps_l1), bool(head))
 
     def _forward_plugin(self, input, target):

@@ -166,7 +166,7 @@ def test_ragged_sizes_all_vector_widths(dev, native, oracle, H, monkeypatch):
     tgt = synth.make_maps(41 + H, B, H)
     ref_l, ref_lg = oracle.rendering_loss(maps, tgt, table)
     for vec in ("1", "2", "4"):
-        for k in ("SVBRDF_K1_VEC", "SVBRDF_K2_VEC", "SVBRDF_K3_VEC"):
+        for k in ("SVBRDF_K1_VEC", "SVBRDF_K2_VEC"):       # K3 is one pixel per thread by design
             monkeypatch.setenv(k, vec)
         assert_render_strict(_np(native.render_fwd(_t(maps, dev), _t(table, dev))), ref_out, "fwd H=%d vec=%s" % (H, vec))
         assert_grad_close(_np(native.render_bwd(_t(maps, dev), _t(table, dev), _t(cot, dev))), ref_g,
@@ -509,6 +509,95 @@ def test_host_extension_and_ctypes_paths_are_bitwise_identical(dev, golden):
     loss.backward(retain_graph=True)
     with pytest.raises(RuntimeError):
         loss.backward()
+
+
+def test_host_scene_table_rides_in_the_kernel_arguments(dev, native, golden):
+    """svbrdf_*_host_scenes: a table of <= 96 rows in HOST memory is passed by value with the launch.
+    Same kernels body, so bitwise the same loss and gradient as the device-table entry points; the
+    host buffer is consumed before the call returns; larger tables are refused by the C ABI and
+    uploaded transparently by the Python wrapper."""
+    lib = native._load()
+    cap = native.host_scenes_max_rows()
+    assert cap == 96
+    from svbrdf_estimation_amd import environment
+    torch.manual_seed(5)
+    for B, S, H in ((3, 5, 20), (8, 12, 8), (1, 96, 9)):          # 15 rows, exactly 96 rows twice
+        table = torch.stack([environment.scene_table(S // 2, S - S // 2) for _ in range(B)])
+        assert B * S <= cap and not table.is_cuda
+        tgt = _t(synth.make_maps(3 * H, B, H), dev)
+        maps = _t(synth.make_maps(3 * H + 1, B, H, tiled_roughness=False), dev)
+        enc = _t(synth.uniform01(H, (B, 9, H, H)) * 2 - 1, dev)
+        for head in (False, True):
+            for l1w in (0.0, 0.1):
+                for want_grad in (True, False):
+                    x = enc if head else maps
+                    l_dev, g_dev = native.rendering_loss(x, tgt, table.to(dev), want_grad=want_grad, l1_weight=l1w, head=head)
+                    l_host, g_host = native.rendering_loss(x, tgt, table, want_grad=want_grad, l1_weight=l1w, head=head)
+                    assert torch.equal(l_dev, l_host), (B, S, head, l1w, want_grad)
+                    if want_grad:
+                        assert torch.equal(g_dev, g_host), (B, S, head, l1w)
+    # raw C ABI: the host buffer may be overwritten as soon as the call has returned
+    B, S, H = 2, 7, 24
+    table = torch.stack([environment.scene_table(3, 4) for _ in range(B)])
+    maps, tgt = _t(synth.make_maps(1, B, H), dev), _t(synth.make_maps(2, B, H), dev)
+    ref_l, ref_g = native.rendering_loss(maps, tgt, table.to(dev))
+    ws = torch.zeros(lib.svbrdf_rendering_loss_workspace_bytes(B, S, H, H) // 8 + 1, dtype=torch.int64, device=dev)
+    loss, grad = torch.empty(1, device=dev), torch.empty_like(maps)
+    xr = native.xrow(dev, H)
+    host = np.ascontiguousarray(table.numpy()).copy()
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    rc = lib.svbrdf_mixed_loss_fwd_bwd_host_scenes(maps.data_ptr(), tgt.data_ptr(), host.ctypes.data, xr.data_ptr(),
+                                                   ctypes.c_float(0.1), ctypes.c_float(0.0), ctypes.c_float(0.01),
+                                                   loss.data_ptr(), grad.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                                   B, S, H, H, st)
+    host[:] = np.nan                                               # would poison a deferred read
+    assert rc == 0, lib.svbrdf_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(loss, ref_l) and torch.equal(grad, ref_g)
+    # one row too many: refused by the ABI ...
+    big = torch.stack([environment.scene_table(48, 49) for _ in range(1)])
+    m1, t1 = _t(synth.make_maps(3, 1, 8), dev), _t(synth.make_maps(4, 1, 8), dev)
+    hb = np.ascontiguousarray(big.numpy())
+    rc = lib.svbrdf_mixed_loss_fwd_bwd_host_scenes(m1.data_ptr(), t1.data_ptr(), hb.ctypes.data, native.xrow(dev, 8).data_ptr(),
+                                                   ctypes.c_float(0.1), ctypes.c_float(0.0), ctypes.c_float(0.01),
+                                                   loss.data_ptr(), None, ws.data_ptr(), ws.numel() * 8, 1, 97, 8, 8, st)
+    assert rc == -2 and b"SVBRDF_HOST_SCENES_MAX_ROWS" in lib.svbrdf_last_error()
+    # ... and uploaded by the wrapper
+    l_up, g_up = native.rendering_loss(m1, t1, big)
+    l_dv, g_dv = native.rendering_loss(m1, t1, big.to(dev))
+    assert torch.equal(l_up, l_dv) and torch.equal(g_up, g_dv)
+    # the C++ host path takes the same two routes
+    from svbrdf_estimation_amd import _hostext
+    ext = _hostext.module()
+    assert ext is not None
+    xa, xb = maps.clone().requires_grad_(True), maps.clone().requires_grad_(True)
+    la = ext.fused_loss_with_scenes(xa, tgt, table, 0.1, 0.1, 0.01, st, False)
+    lb = ext.fused_loss_with_scenes(xb, tgt, table.to(dev), 0.1, 0.1, 0.01, st, False)
+    la.backward(); lb.backward()
+    assert torch.equal(la, lb) and torch.equal(xa.grad, xb.grad)
+    with pytest.raises(RuntimeError):
+        ext.fused_loss_with_scenes(m1, t1, big, 0.1, 0.0, 0.01, st, False)
+    # module level, a table too large for the argument block (2 x 50 rows): both host paths upload it
+    from svbrdf_estimation_amd import losses, renderers
+    res = []
+    try:
+        for enabled in (True, False):
+            _hostext.set_enabled(enabled)
+            fn = losses.RenderingLoss(renderers.LocalRenderer())
+            fn.random_configuration_count, fn.specular_configuration_count = 20, 30
+            x = maps.clone().requires_grad_(True)
+            torch.manual_seed(11)
+            l = fn(x, tgt)
+            l.backward()
+            res.append((l.detach().clone(), x.grad.clone()))
+    finally:
+        _hostext.set_enabled(True)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    torch.manual_seed(11)
+    tab = torch.stack([environment.scene_table(20, 30) for _ in range(B)])
+    l_ref, g_ref = native.rendering_loss(maps, tgt, tab.to(dev))
+    assert torch.equal(res[0][0], l_ref.view(())) and torch.equal(res[0][1], g_ref)
 
 
 # ---------------------------------------------------------------- row f1: network head fused into the loss
