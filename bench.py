@@ -267,7 +267,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "frac_of_measured_copy_peak": achieved / 6290.0,   # MI355X_MICROARCH.md: float4 copy
-                         "kernel": "k_rendering_loss<GRAD=true,L1=false,HEAD=false> (single launch: both shadings, log/L1, adjoint, loss finalise)",
+                         "kernel": "%s<GRAD=true,L1=false,HEAD=false> (single launch: both shadings, log/L1, adjoint, loss finalise)"
+                                   % ("k_rendering_loss_inl" if B * S <= _native.host_scenes_max_rows() else "k_rendering_loss"),
+                         "scene_table": "by value in the kernel-argument block (no H2D command)"
+                                        if B * S <= _native.host_scenes_max_rows() else "pinned-ring upload",
                          "kernel_limited_patches_per_s": B / (kernel_ms_avg * 1e-3),
                          "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
                          "kernel_launches_timed": len(kernel_ms),

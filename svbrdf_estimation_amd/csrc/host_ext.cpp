@@ -3,9 +3,10 @@
 // The Python host path (environment.BatchSceneSampler + ctypes + torch.autograd.Function) costs
 // 160-220 us per call on the GPU box, 3x the fused kernel it launches.  This extension does the
 // same three things -- draw the scenes (reference RNG order, development/multiImage_pytorch/
-// losses.py:35 -> environment.py:18-55 -> utils.py:100-111), upload the [B,S,9] table through a
-// pinned ring, launch svbrdf_{rendering,mixed}_loss_fwd_bwd and hang the precomputed gradient on a
-// C++ autograd node -- without the Python interpreter in the loop.  It contains no arithmetic of
+// losses.py:35 -> environment.py:18-55 -> utils.py:100-111), hand the [B,S,9] table to the kernel
+// (by value with the launch when it has <= 96 rows, through a pinned upload ring otherwise), launch
+// svbrdf_{mixed,head}_loss_fwd_bwd[_host_scenes] and hang the precomputed gradient on a C++
+// autograd node -- without the Python interpreter in the loop.  It contains no arithmetic of
 // the hot path: the kernels live in libsvbrdf_hip.so and are reached through the C ABI
 // (include/svbrdf_hip.h), whose entry points are resolved with dlsym.  No HIP/ROCm headers are
 // needed: the raw stream handle comes from Python, events use three runtime symbols by name.

@@ -19,7 +19,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTI
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_SMEM -d $OUT/${TAG}_pmc_sq2 --output-format csv -- $BENCH --steps 20 --warmup 5 > $OUT/${TAG}_pmc_sq2.log 2>&1
 cd $R
 # un-profiled bench line (with the CPU baseline) -- never compare profiled and un-profiled timings
-timeout 400 python3 bench.py --steps 300 --warmup 30 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+timeout 400 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 timeout 200 python3 tools/k3_sweep.py > $OUT/${TAG}_k3_sweep.txt 2>&1
 timeout 200 python3 tools/k12_bench.py > $OUT/${TAG}_k12_bench.txt 2>&1
 [ -x tools/_build/valu_rate ] && timeout 100 tools/_build/valu_rate > $OUT/${TAG}_valu_rate.txt 2>&1
