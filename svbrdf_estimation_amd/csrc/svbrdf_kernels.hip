@@ -68,7 +68,8 @@ __device__ __forceinline__ float rsq_(float x) { return __builtin_amdgcn_rsqf(x)
 // 3 x 2^31 operand pairs (tests/test_gpu_parity.py).
 // Timing experiments only (tools/ablate.sh builds separate libraries with -DSVBRDF_ABLATE=n; results
 // are WRONG by construction): 1 = inexact geometry (rsq*x instead of exact sqrt/division),
-// 2 = no target shading, 3 = no logs in the loss, 4 = no adjoint, 5 = no GGX/Smith lobe.
+// 2 = no target shading, 3 = no logs in the loss, 4 = no adjoint, 5 = no GGX/Smith lobe,
+// 6 = no map loads in K3 (values synthesised from the pixel index), 7 = no gradient stores in K3.
 #ifndef SVBRDF_ABLATE
 #define SVBRDF_ABLATE 0
 #endif
@@ -743,6 +744,14 @@ __device__ __forceinline__ void head_bwd(const Head &h, const Grad &g, float ge[
     ge[5] = 0.5f * ((g.r[0] + g.r[1]) + g.r[2]);
 }
 
+// ablation 6 only: plausible map values without touching memory
+__device__ __forceinline__ void fake_maps(size_t pix, float shift, Maps &m)
+{
+    const float t = (float)(pix & 1023) * (1.0f / 2048.0f) + shift;     // [0, 0.55)
+    m.n[0] = 0.1f * t; m.n[1] = 0.2f - 0.1f * t; m.n[2] = 0.97f;
+    for (int k = 0; k < 3; ++k) { m.d[k] = 0.2f + 0.5f * t; m.r[k] = 0.3f + t; m.s[k] = 0.1f + 0.25f * t * (float)(k + 1); }
+}
+
 // One thread = one pixel (VEC = 1: the kernel is VALU-bound, wider loads measured no gain
 // and cost occupancy).  WITH_L1 adds SVBRDFL1Loss on the 24 values already in registers.
 template <bool WITH_GRAD, bool WITH_L1, bool HEAD>
@@ -775,9 +784,11 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
             for (int k = 0; k < 9; ++k) e[k] = ip[(size_t)k * plane];
             head = decode_head(e, in[0]);
         } else {
-            load_maps<1>(input + (size_t)b * 12 * plane, plane, pix, in);
+            if (SVBRDF_ABLATE == 6) fake_maps(pix, 0.0f, in[0]);
+            else load_maps<1>(input + (size_t)b * 12 * plane, plane, pix, in);
         }
-        load_maps<1>(target + (size_t)b * 12 * plane, plane, pix, tg);
+        if (SVBRDF_ABLATE == 6) fake_maps(pix, 0.05f, tg[0]);
+        else load_maps<1>(target + (size_t)b * 12 * plane, plane, pix, tg);
         Grad acc;
         zero_grad(acc);
         float l1sum = 0.0f;
@@ -817,7 +828,8 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
                 for (int k = 0; k < 9; ++k) gp[(size_t)k * plane] = ge[k];
             } else {
                 const Grad out[1] = {acc};
-                store_grads<1>(grad_input + (size_t)b * 12 * plane, plane, pix, out);
+                if (SVBRDF_ABLATE != 7 || lsum == -12345.0f)
+                    store_grads<1>(grad_input + (size_t)b * 12 * plane, plane, pix, out);
             }
         }
     }
