@@ -80,7 +80,7 @@ __device__ __forceinline__ float log2_(float x) { return SVBRDF_ABLATE == 8 ? x 
 #define SVBRDF_ABLATE 0
 #endif
 #ifndef SVBRDF_LOG_PER_TERM
-#define SVBRDF_LOG_PER_TERM 0      // 1: log(ai) - log(at) with two v_log per channel (A/B builds)
+#define SVBRDF_LOG_PER_TERM 0      // 1: two v_log and one v_rcp per channel, the reference's operation order (A/B builds)
 #endif
 #ifndef SVBRDF_TIMING
 #define SVBRDF_TIMING 0            // 1: timing-only build, see tools/k3_cycles.py
@@ -625,24 +625,42 @@ __device__ __forceinline__ void loss_pixel_scene(const VConst &K, const Geom &g,
     Lobe li[NL];
     float Fi[3], fi[3], ri[3], g_rad[3];
     shade<NL, WITH_GRAD>(K, g, mi, di, li, Fi, fi, ri);
+    // losses.py:46-50: |log(ri + eps) - log(rt + eps)| and its derivative sign/(N (ri + eps)).
+    // Transcendentals are what this kernel pays most for (~16 issue cycles each against ~2.5 for a
+    // plain instruction once several waves share the SIMD: tools/k3_cycles.py),
+    // so the nine of the reference's formulation (six logs, three reciprocals) are done with four:
+    //  * the three 1/ai come from ONE v_rcp of their product (6 multiplies).  Operands are scaled
+    //    by 2^-10 (exact) so that the product stays in range for eps <= ai <= 7e15, eps >= 1e-9
+    //    (checked on the host);
+    //  * log(ai) - log(at) = -log(at/ai): one log per channel on the quotient formed with that 1/ai.
+    // ai == at must give exactly 0 like the reference's log(x) - log(x) (identical maps: zero loss,
+    // zero gradient, sign(0) = 0), hence the explicit select.
+    {
+        constexpr float c = 9.765625e-04f;               // 2^-10
+        const float ec = eps * c, nc = inv_count * c;
+        float b[3], bt[3], ib[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        // losses.py:46-50: |log(ri + eps) - log(rt + eps)|.  The adjoint needs 1/ai anyway, so the
-        // difference of the two logs is taken as ONE log of the quotient at/ai: 2 transcendentals per
-        // channel instead of 3.  (A transcendental costs the SIMD ~16 issue cycles against ~2.5 for a
-        // plain instruction once several waves share it -- tools/k3_cycles.py, DESIGN.md section 4 --
-        // so this is worth 3.6 % of the kernel.)  ai == at must give exactly 0, like the reference's
-        // log(x) - log(x) (identical maps: zero loss, zero gradient, sign(0) = 0): explicit select.
-        const float ai = ri[k] + eps, at = rt[k] + eps;
-        const float iai = rcp_(ai);
-        float delta;
-        if (SVBRDF_ABLATE == 3) delta = ai - at;
-        else if (SVBRDF_LOG_PER_TERM) delta = K.ln2 * (log2_(ai) - log2_(at));     // the reference's operation order
-        else delta = (ai == at) ? 0.0f : -K.ln2 * log2_(at * iai);
-        lsum += fabsf(delta);
-        // d|delta|/d ri = sign(delta)/(N*ai), sign(0) = 0 as in torch
-        const float sg = __builtin_amdgcn_fmed3f(delta * K.huge, -1.0f, 1.0f);
-        g_rad[k] = sg * (inv_count * iai);
+        for (int k = 0; k < 3; ++k) { b[k] = fma_(ri[k], c, ec); bt[k] = fma_(rt[k], c, ec); }   // = (r + eps) * c, one rounding
+        if (SVBRDF_LOG_PER_TERM) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ib[k] = rcp_(b[k]);
+        } else {
+            const float P = b[0] * b[1];
+            const float r = rcp_(P * b[2]);
+            const float t = r * b[2];
+            ib[0] = t * b[1]; ib[1] = t * b[0]; ib[2] = r * P;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float delta;
+            if (SVBRDF_ABLATE == 3) delta = b[k] - bt[k];
+            else if (SVBRDF_LOG_PER_TERM) delta = K.ln2 * (log2_(b[k]) - log2_(bt[k]));     // the reference's operation order
+            else delta = (b[k] == bt[k]) ? 0.0f : -K.ln2 * log2_(bt[k] * ib[k]);
+            lsum += fabsf(delta);
+            // d|delta|/d ri = sign(delta)/(N*ai), sign(0) = 0 as in torch
+            const float sg = __builtin_amdgcn_fmed3f(delta * K.huge, -1.0f, 1.0f);
+            g_rad[k] = sg * (nc * ib[k]);
+        }
     }
     if (SVBRDF_ABLATE == 4) {
         acc.n[0] += g_rad[0]; acc.n[1] += g_rad[1]; acc.n[2] += g_rad[2];
@@ -1109,6 +1127,8 @@ static int loss_impl(const char *who, bool head, bool scenes_on_host, const floa
 {
     if (!input || !target || !scenes || !xrow || !loss_out || !workspace) return fail(SVBRDF_ERR_NULL, who);
     if (int e = check_dims(B, S, H, W)) return e;
+    if (!(eps >= 1e-9f) || !(eps <= 1e9f))
+        return fail(SVBRDF_ERR_DIMS, "loss: eps_render must lie in [1e-9, 1e9] (the reference uses 0.1)");
     if (scenes_on_host && (long long)B * S > SVBRDF_HOST_SCENES_MAX_ROWS)
         return fail(SVBRDF_ERR_DIMS, "host_scenes: B*S exceeds SVBRDF_HOST_SCENES_MAX_ROWS (upload the table and use the device-pointer entry)");
     if (!aligned(input, 4) || !aligned(target, 4) || !aligned(scenes, 4) || !aligned(xrow, 4) ||

@@ -76,6 +76,9 @@ def test_abi_error_codes(dev, native):
     assert need >= 8
     assert lib.svbrdf_rendering_loss_fwd_bwd(p, p, p, p, ctypes.c_float(0.1), p, p, p, need - 1, 1, 1, 4, 4, None) == -4
     assert b"workspace" in lib.svbrdf_last_error()
+    for bad_eps in (0.0, 1e-12, float("nan"), 1e12):
+        assert lib.svbrdf_rendering_loss_fwd_bwd(p, p, p, p, ctypes.c_float(bad_eps), p, p, p, need, 1, 1, 4, 4, None) == -2
+    assert b"eps_render" in lib.svbrdf_last_error()
 
 
 def test_device_division_and_sqrt_are_correctly_rounded(dev, native):
