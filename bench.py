@@ -177,8 +177,9 @@ def main():
 
     # HIP events around the kernel launch on the launch stream, on every `stride`-th timed step (a timing
     # event is an end-of-pipe timestamp: bracketing EVERY launch costs ~10 us of GPU idle per step once the
-    # loop is GPU-bound, so the launches are sampled instead; at least 25 samples)
-    stride = max(1, min(4, args.steps // 25))
+    # loop is GPU-bound, so the launches are sampled instead: every 16th at the default 2000 steps = 125 samples,
+    # never fewer than ~25)
+    stride = max(1, min(16, args.steps // 100, max(1, args.steps // 25)))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           if i % stride == 0 else None for i in range(args.steps)]
     state = {"i": -1}
