@@ -54,14 +54,14 @@ def parse_args():
     return ap.parse_args()
 
 
-def synthetic_maps(gen, B, H):
+def synthetic_maps(gen, B, H, rough_min=0.0, tied=True):
     """BASELINE.md section 3: normals = normalize(0.3N, 0.3N, 1+|0.3N|); diffuse, specular ~ U(0,1);
-    roughness ~ U(0,1) one channel tiled x3."""
+    roughness ~ U(rough_min,1), one channel tiled x3 (model-like) unless tied=False."""
     n = torch.randn(B, 3, H, H, generator=gen) * 0.3
     n[:, 2] = 1.0 + n[:, 2].abs()
     n = n / n.norm(dim=1, keepdim=True)
     d = torch.rand(B, 3, H, H, generator=gen)
-    r = torch.rand(B, 1, H, H, generator=gen).expand(B, 3, H, H)
+    r = torch.rand(B, 1 if tied else 3, H, H, generator=gen).expand(B, 3, H, H) * (1.0 - rough_min) + rough_min
     s = torch.rand(B, 3, H, H, generator=gen)
     return torch.cat((n, d, r, s), dim=1).contiguous()
 
@@ -144,6 +144,32 @@ def secondary_kernels(dev, H):
         gbps = nbytes / (ms * 1e-3) / 1e9
         out[name] = {"renders_per_launch": B, "ms_per_launch": ms, "algorithmic_GBps": gbps,
                      "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "renders_per_s": B / (ms * 1e-3)}
+    del maps, cot
+    # K3 alone (kernel-limited rates): sensitivity to the roughness distribution at config 2, the
+    # three-lobe path (independent roughness channels), and config 5 (512x512, 11 + 21 scenes)
+    def k3(tag, B, Hk, n_random, n_specular, **kw):
+        g = torch.Generator().manual_seed(11)
+        a, t = synthetic_maps(g, B, Hk, **kw).to(dev), synthetic_maps(g, B, Hk, **kw).to(dev)
+        torch.manual_seed(11)
+        tab = environment.BatchSceneSampler(B, n_random, n_specular).sample()
+        tab = tab if B * (n_random + n_specular) <= _native.host_scenes_max_rows() else tab.to(dev)
+        call = lambda: _native.rendering_loss(a, t, tab, 0.1, want_grad=True)
+        for _ in range(5):
+            call()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            call()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / 20            # back-to-back launches, host overhead of the ctypes path included
+        gb = 144.0 * Hk * Hk * B / (ms * 1e-3) / 1e9
+        out[tag] = {"B": B, "H": Hk, "scenes": n_random + n_specular, "ms_per_launch": ms,
+                    "patches_per_s": B / (ms * 1e-3), "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBPS}
+    k3("K3_config2_roughness_U(0.2,1)", 8, H, 3, 6, rough_min=0.2)
+    k3("K3_config2_untied_roughness", 8, H, 3, 6, tied=False)
+    k3("K3_config5_512_32scenes", 8, 512, 11, 21)
     return out
 
 
