@@ -32,7 +32,11 @@ if __name__ == "__main__":
     for (B, H, S, tied, grad) in cfgs:
         inp, tgt = maps(B, H, gen, tied).to(dev), maps(B, H, gen, tied).to(dev)
         torch.manual_seed(0)
-        table = environment.BatchSceneSampler(B, S // 3, S - S // 3).sample().to(dev)
+        table = environment.BatchSceneSampler(B, S // 3, S - S // 3).sample()
+        # the step path hands tables of <= 96 rows over by value (k_rendering_loss_inl); SWEEP_DEVICE_TABLE=1 times
+        # the device-pointer kernel instead
+        if os.environ.get("SWEEP_DEVICE_TABLE") or B * S > _native.host_scenes_max_rows():
+            table = table.to(dev)
         us = timeit(lambda: _native.rendering_loss(inp, tgt, table, 0.1, want_grad=grad))
         px = B * H * H
         print("B=%-3d H=%-4d S=%-3d tied=%d grad=%d  %8.1f us  %7.2f ns/pixel  %6.3f ns/pixel-scene  alg %.0f GB/s" % (
