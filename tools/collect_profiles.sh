@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --no-cpu-baseline"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-secondary"
 # kernel-trace + stats (no counters in this pass)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats --output-format csv -- $BENCH --steps 200 --warmup 20 > $OUT/${TAG}_stats.log 2>&1
 # HBM traffic: FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots)
