@@ -34,6 +34,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_VALU_PEAK_TFLOPS = 157.3   # ditto, packed-FMA vector peak
 FLOP_PER_PIXEL_SCENE = 573.0    # SURVEY.md 8d (div/sqrt/log/pow counted as 1)
+K3_CLOCK_GHZ = 2.11             # s_memtime / s_memrealtime inside K3 (tools/k3_cycles.py, profiles/r01_k3_cycles.txt)
 
 
 def parse_args():
@@ -270,7 +271,7 @@ def main():
         patches = world * B * args.steps
         alg_bytes = 144.0 * H * H * B                 # per launch: 36 planes x 4 B per patch
         achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
-        traffic = None
+        traffic = valu_issue = None
         tpath = os.path.join(ROOT, "profiles", "k3_hbm_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -278,8 +279,18 @@ def main():
                     tj = json.load(f)
                 if tj.get("B") == B and tj.get("H") == H and tj.get("S") == S:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    if tj.get("valu_wave_instr_per_launch"):
+                        # what actually bounds K3: wave64 VALU instructions issued (PMC SQ_INSTS_VALU of the same
+                        # kernel, profiles/) against the SIMD-32 issue peak of one per 2 cycles per SIMD
+                        # (MI355X_MICROARCH.md), 1024 SIMDs, at the clock the chip holds under this kernel
+                        rate = tj["valu_wave_instr_per_launch"] / (kernel_ms_avg * 1e-3)
+                        peak = 1024 * K3_CLOCK_GHZ * 1e9 / 2.0
+                        valu_issue = {"wave_instr_per_launch": tj["valu_wave_instr_per_launch"],
+                                      "of_which_transcendental": tj.get("trans_wave_instr_per_launch"),
+                                      "achieved_wave_instr_per_s": rate, "peak_wave_instr_per_s": peak,
+                                      "frac": rate / peak, "clock_GHz_under_kernel": K3_CLOCK_GHZ}
             except Exception:
-                traffic = None
+                traffic = valu_issue = None
         out = {
             "metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)",
             "value": patches / elapsed, "unit": "patches/s", "n_gpus": world,
@@ -303,7 +314,8 @@ def main():
                          "kernel_launches_timed": len(kernel_ms),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "valu_frac_of_fp32_peak": (FLOP_PER_PIXEL_SCENE * H * H * S * B / (kernel_ms_avg * 1e-3))
-                                                   / (FP32_VALU_PEAK_TFLOPS * 1e12)},
+                                                   / (FP32_VALU_PEAK_TFLOPS * 1e12),
+                         "valu_issue": valu_issue},
             "loss": mean_loss,
             "host_path": "native C++ extension (csrc/host_ext.cpp)" if ext is not None else "python + ctypes",
             "autograd_engine": "multithreaded" if args.engine_threads else "calling thread",

@@ -54,6 +54,9 @@ if k3 and "FETCH_SIZE" in summary[k3] and "WRITE_SIZE" in summary[k3]:
                "hbm_bytes_per_launch": 2.0 * fetch_kib * 1024.0 + write_kib * 1024.0,
                "correction": "gfx950: FETCH_SIZE x2 for coalesced streaming reads (MI355X_MICROARCH.md, HBM)",
                "B": cfg.get("global_batch"), "H": cfg.get("H"), "S": cfg.get("scenes"), "round": tag}
+    for key, counter in (("valu_wave_instr_per_launch", "SQ_INSTS_VALU"), ("trans_wave_instr_per_launch", "SQ_INSTS_VALU_TRANS_F32")):
+        if counter in summary[k3]:
+            traffic[key] = summary[k3][counter]["mean"]
     json.dump(traffic, open(os.path.join(P, "k3_hbm_traffic.json"), "w"), indent=1)
     summary["_k3_traffic"] = traffic
 json.dump(summary, open(os.path.join(P, "%s_pmc_summary.json" % tag), "w"), indent=1, sort_keys=True)
