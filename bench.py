@@ -48,6 +48,11 @@ def parse_args():
     ap.add_argument("--specular-scenes", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the K1/K2 stand-alone rates (N=1 only)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo only for plumbing tests of the "
+                         "multi-rank control flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank uses cuda:0 (plumbing tests only, with --backend gloo)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     ap.add_argument("--engine-threads", action="store_true",
                     help="keep PyTorch's multithreaded backward engine (default: run backward on the calling thread; "
@@ -182,13 +187,25 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    nccl = args.backend == "nccl"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm
+        if nccl:
+            dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo")
+
+    def barrier():
+        if nccl:
+            dist.barrier(device_ids=[local_rank])
+        else:
+            dist.barrier()
 
     from svbrdf_estimation_amd import _native, distributed, losses, renderers
 
@@ -243,7 +260,7 @@ def main():
         step()
     torch.cuda.synchronize(dev)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -252,15 +269,15 @@ def main():
     state["i"] = -1
     torch.cuda.synchronize(dev)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     _native.set_launch_hook(None)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mean_loss = distributed.global_mean(last.detach()).item()
+        mean_loss = distributed.global_mean(last.detach() if nccl else last.detach().cpu()).item()
     else:
         mean_loss = last.item()
 
