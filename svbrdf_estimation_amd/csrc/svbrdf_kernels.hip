@@ -166,7 +166,10 @@ __device__ __forceinline__ Geom geometry(const VConst &K, const float sc[9], flo
     const Recip il = length_rn(dot3(rlx, rly, rlz, rlx, rly, rlz), yl);
     g.wox = div_rn(rcx, ic); g.woy = div_rn(rcy, ic); g.woz = div_rn(rcz, ic);
     g.wix = div_rn(rlx, il); g.wiy = div_rn(rly, il); g.wiz = div_rn(rlz, il);
-    const float sx = (g.wix + g.wox) * 0.5f, sy = (g.wiy + g.woy) * 0.5f, sz = (g.wiz + g.woz) * 0.5f;
+    // h = normalize((wi + wo)/2) (renderers.py:45): the halving is exact and commutes with every rounding
+    // that follows (products scale by 4, the correctly rounded sqrt by 2, the quotients not at all), so
+    // normalize(wi + wo) gives the same bits without the three multiplies
+    const float sx = g.wix + g.wox, sy = g.wiy + g.woy, sz = g.wiz + g.woz;
     const Recip ih = length_rn(dot3(sx, sy, sz, sx, sy, sz), yh);
     g.hx = div_rn(sx, ih); g.hy = div_rn(sy, ih); g.hz = div_rn(sz, ih);
     // from here on the computation is well conditioned: 1-ULP primitives are enough
