@@ -845,19 +845,46 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         zero_grad(acc);
         float l1sum = 0.0f;
         if (WITH_L1) {
+            // losses.py:7-19.  Same economy of transcendentals as in loss_pixel_scene: the six 1/(x + eps)
+            // of the log terms' derivatives come from ONE v_rcp of their product (all six lie in
+            // [eps_l1, 1 + eps_l1]: no scaling needed), and log(a) - log(b) is one log of the quotient formed
+            // with that reciprocal (equal operands select exactly 0): 7 transcendentals per pixel instead of 18.
+            float a[6], b[6], ia[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                a[k] = in[0].d[k] + l1.eps; b[k] = tg[0].d[k] + l1.eps;
+                a[3 + k] = in[0].s[k] + l1.eps; b[3 + k] = tg[0].s[k] + l1.eps;
+            }
+            if (SVBRDF_LOG_PER_TERM) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) ia[k] = rcp_(a[k]);
+            } else {
+                float pre[6];               // prefix products a0, a0 a1, ...
+                pre[0] = a[0];
+#pragma unroll
+                for (int k = 1; k < 6; ++k) pre[k] = pre[k - 1] * a[k];
+                float r = rcp_(pre[5]);     // 1/(a0 ... a5)
+#pragma unroll
+                for (int k = 5; k > 0; --k) { ia[k] = r * pre[k - 1]; r *= a[k]; }
+                ia[0] = r;
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float dn = in[0].n[k] - tg[0].n[k], dr = in[0].r[k] - tg[0].r[k];
-                const float adi = in[0].d[k] + l1.eps, adt = tg[0].d[k] + l1.eps;
-                const float asi = in[0].s[k] + l1.eps, ast = tg[0].s[k] + l1.eps;
-                const float dd = kLn2 * (log2_(adi) - log2_(adt));
-                const float ds = kLn2 * (log2_(asi) - log2_(ast));
+                float dd, ds;
+                if (SVBRDF_LOG_PER_TERM) {
+                    dd = kLn2 * (log2_(a[k]) - log2_(b[k]));
+                    ds = kLn2 * (log2_(a[3 + k]) - log2_(b[3 + k]));
+                } else {
+                    dd = (a[k] == b[k]) ? 0.0f : -kLn2 * log2_(b[k] * ia[k]);
+                    ds = (a[3 + k] == b[3 + k]) ? 0.0f : -kLn2 * log2_(b[3 + k] * ia[3 + k]);
+                }
                 l1sum += (fabsf(dn) + fabsf(dr)) + (fabsf(dd) + fabsf(ds));
                 if (WITH_GRAD) {
                     acc.n[k] = signed_scale(dn, l1.grad_scale);
                     acc.r[k] = signed_scale(dr, l1.grad_scale);
-                    acc.d[k] = signed_scale(dd, l1.grad_scale) * rcp_(adi);
-                    acc.s[k] = signed_scale(ds, l1.grad_scale) * rcp_(asi);
+                    acc.d[k] = signed_scale(dd, l1.grad_scale) * ia[k];
+                    acc.s[k] = signed_scale(ds, l1.grad_scale) * ia[3 + k];
                 }
             }
         }
