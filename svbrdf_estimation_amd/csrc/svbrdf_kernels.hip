@@ -732,7 +732,7 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt,
     if (WITH_GRAD) {        // timing build: the normal-gradient planes carry loop cycles / 100 MHz ticks / start stamp
         acc.n[0] = (float)(clock64() - tm0);
         acc.n[1] = (float)(wall_clock64() - wc0);
-        acc.n[2] = (float)(tm0 & 0xffffff);
+        acc.n[2] = (float)(wc0 & 0xffffff);        // 100 MHz ticks, one clock for the whole chip
     }
 #endif
     return lsum;
