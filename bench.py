@@ -48,6 +48,10 @@ def parse_args():
     ap.add_argument("--specular-scenes", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the K1/K2 stand-alone rates (N=1 only)")
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="untimed device settle phase before the W warm-up steps: the same step function is run for "
+                         "this long so that clocks (DVFS) and caches are in their steady state even when W is small; "
+                         "reported in the JSON line")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only for plumbing tests of the "
                          "multi-rank control flow on a box with fewer GPUs than ranks)")
@@ -222,8 +226,8 @@ def main():
     # HIP events around the kernel launch on the launch stream, on every `stride`-th timed step (a timing
     # event is an end-of-pipe timestamp: bracketing EVERY launch costs ~10 us of GPU idle per step once the
     # loop is GPU-bound, so the launches are sampled instead: every 16th at the default 2000 steps = 125 samples,
-    # never fewer than ~25)
-    stride = max(1, min(16, args.steps // 100, max(1, args.steps // 25)))
+    # and at least ~5 samples however few steps are asked for)
+    stride = max(1, min(16, args.steps // 5))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           if i % stride == 0 else None for i in range(args.steps)]
     state = {"i": -1}
@@ -256,6 +260,11 @@ def main():
 
     if not args.engine_threads:
         torch.autograd.set_multithreading_enabled(False)
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:      # untimed, see --settle-ms
+        for _ in range(64):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -336,6 +345,7 @@ def main():
             "loss": mean_loss,
             "host_path": "native C++ extension (csrc/host_ext.cpp)" if ext is not None else "python + ctypes",
             "autograd_engine": "multithreaded" if args.engine_threads else "calling thread",
+            "settle_ms": args.settle_ms,
         }
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_kernels(dev, H)
