@@ -35,6 +35,19 @@
 
 #include "svbrdf_hip.h"
 
+// Translation units.  The scheduler options that suit the forward+adjoint variants of the fused loss kernel (no
+// post-RA scheduling, max-memory-clause strategy: -6 ... -14 % on them) cost the HBM-bound K2 13 % and the
+// forward-only loss kernels 6 %, which prefer a bottom-up post-RA scheduler (measured).  The
+// Makefile therefore compiles this file twice and links both objects into libsvbrdf_hip.so:
+//   SVBRDF_TU=0  everything except the forward+adjoint loss kernels
+//   SVBRDF_TU=1  only those kernels and their launcher
+// SVBRDF_TU=2 (default; tools/ build the file with one command): everything in one unit.
+#ifndef SVBRDF_TU
+#define SVBRDF_TU 2
+#endif
+#define SVBRDF_TU_MAIN (SVBRDF_TU != 1)
+#define SVBRDF_TU_ADJOINT (SVBRDF_TU != 0)
+
 namespace {
 
 constexpr int kThreads = 256;          // 4 waves of 64 (K1, K2)
@@ -992,6 +1005,7 @@ __global__ SVBRDF_K3_ATTRS void k_rendering_loss_inl([[maybe_unused]] const Scen
                                                   l1, grad_input, ws, loss_out, S, H, W);
 }
 
+#if SVBRDF_TU_MAIN
 // data[i] *= *scale, skipped entirely (no memory traffic) when *scale == 1: lets the autograd
 // wrapper apply an upstream gradient that lives on the device without a host sync.
 __global__ __launch_bounds__(kThreads) void k_scale_inplace(float *__restrict__ data, const float *__restrict__ scale,
@@ -1095,8 +1109,56 @@ dim3 grid_for(int B, int H, int W, int vec)
     return dim3((unsigned)((plane + per_block - 1) / per_block), (unsigned)B, 1);
 }
 
+#endif  // SVBRDF_TU_MAIN
+
+
+// launches one K3 variant; `rows` = the host scene table for the by-value kernels (NULL: device table `scenes`)
+template <bool G>
+void launch_k3(bool with_l1, bool head, const float *rows, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st,
+               const float *input, const float *target, const float *scenes, const float *xrow, float eps,
+               float inv_count, double loss_scale, float fixed_scale, L1Params l1, float *grad_input,
+               unsigned long long *ws, float *loss_out, int B, int S, int H, int W)
+{
+    SceneBlock block_arg;      // only the first B*S rows are ever read
+    if (rows) std::memcpy(block_arg.v, rows, (size_t)B * S * 9 * sizeof(float));
+#define SVBRDF_LAUNCH_K3(L, HD)                                                                                 \
+    do {                                                                                                        \
+        if (rows)                                                                                               \
+            hipLaunchKernelGGL((k_rendering_loss_inl<G, L, HD>), grid, block, lds_bytes, st, block_arg, input,   \
+                               target, xrow, eps, inv_count, loss_scale, fixed_scale, l1, grad_input, ws,       \
+                               loss_out, S, H, W);                                                              \
+        else                                                                                                    \
+            hipLaunchKernelGGL((k_rendering_loss<G, L, HD>), grid, block, lds_bytes, st, input, target, scenes, \
+                               xrow, eps, inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, S,  \
+                               H, W);                                                                           \
+    } while (0)
+    if (head) { if (with_l1) SVBRDF_LAUNCH_K3(true, true); else SVBRDF_LAUNCH_K3(false, true); }
+    else { if (with_l1) SVBRDF_LAUNCH_K3(true, false); else SVBRDF_LAUNCH_K3(false, false); }
+#undef SVBRDF_LAUNCH_K3
+}
+
 }  // namespace
 
+// the forward+adjoint variants live in their own translation unit (see the top of this file)
+extern "C" __attribute__((visibility("hidden"))) void svbrdf_internal_launch_k3_adjoint(
+    int with_l1, int head, const float *rows, unsigned gx, unsigned gy, size_t lds_bytes, void *stream, const float *input,
+    const float *target, const float *scenes, const float *xrow, float eps, float inv_count, double loss_scale,
+    float fixed_scale, float l1_sum_scale, float l1_grad_scale, float l1_eps, float *grad_input, unsigned long long *ws,
+    float *loss_out, int B, int S, int H, int W);
+#if SVBRDF_TU_ADJOINT
+void svbrdf_internal_launch_k3_adjoint(int with_l1, int head, const float *rows, unsigned gx, unsigned gy, size_t lds_bytes,
+                                       void *stream, const float *input, const float *target, const float *scenes,
+                                       const float *xrow, float eps, float inv_count, double loss_scale, float fixed_scale,
+                                       float l1_sum_scale, float l1_grad_scale, float l1_eps, float *grad_input,
+                                       unsigned long long *ws, float *loss_out, int B, int S, int H, int W)
+{
+    launch_k3<true>(with_l1 != 0, head != 0, rows, dim3(gx, gy, 1), dim3(kLossThreads), lds_bytes,
+                    static_cast<hipStream_t>(stream), input, target, scenes, xrow, eps, inv_count, loss_scale, fixed_scale,
+                    L1Params{l1_sum_scale, l1_grad_scale, l1_eps}, grad_input, ws, loss_out, B, S, H, W);
+}
+#endif
+
+#if SVBRDF_TU_MAIN
 extern "C" {
 
 int svbrdf_abi_version(void) { return SVBRDF_ABI_VERSION; }
@@ -1189,31 +1251,14 @@ static int loss_impl(const char *who, bool head, bool scenes_on_host, const floa
     const size_t lds_bytes = grad_input ? 0 : (size_t)S * 9 * sizeof(float);   // forward-only kernels stage scenes in LDS
     if (lds_bytes > 60 * 1024) return fail(SVBRDF_ERR_DIMS, "loss: too many scenes per item for the LDS stage (max 1706)");
     const L1Params l1{l1_weight * (float)S, (float)((double)l1_weight / ((double)B * 3.0 * (double)plane)), eps_l1};
-    SceneBlock block_arg;      // only the first B*S rows are ever read
-    if (scenes_on_host) std::memcpy(block_arg.v, scenes, (size_t)B * S * 9 * sizeof(float));
-#define SVBRDF_LAUNCH_K3(G, L, HD)                                                                              \
-    do {                                                                                                        \
-        if (scenes_on_host)                                                                                     \
-            hipLaunchKernelGGL((k_rendering_loss_inl<G, L, HD>), grid, block, lds_bytes, st, block_arg, input,   \
-                               target, xrow, eps, inv_count, loss_scale, fixed_scale, l1, grad_input, ws,       \
-                               loss_out, S, H, W);                                                              \
-        else                                                                                                    \
-            hipLaunchKernelGGL((k_rendering_loss<G, L, HD>), grid, block, lds_bytes, st, input, target, scenes, \
-                               xrow, eps, inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, S,  \
-                               H, W);                                                                           \
-    } while (0)
-    const int variant = (head ? 4 : 0) | (l1_weight != 0.0f ? 2 : 0) | (grad_input ? 1 : 0);
-    switch (variant) {
-    case 0: SVBRDF_LAUNCH_K3(false, false, false); break;
-    case 1: SVBRDF_LAUNCH_K3(true, false, false); break;
-    case 2: SVBRDF_LAUNCH_K3(false, true, false); break;
-    case 3: SVBRDF_LAUNCH_K3(true, true, false); break;
-    case 4: SVBRDF_LAUNCH_K3(false, false, true); break;
-    case 5: SVBRDF_LAUNCH_K3(true, false, true); break;
-    case 6: SVBRDF_LAUNCH_K3(false, true, true); break;
-    default: SVBRDF_LAUNCH_K3(true, true, true); break;
-    }
-#undef SVBRDF_LAUNCH_K3
+    const float *rows = scenes_on_host ? scenes : nullptr;
+    if (grad_input)
+        svbrdf_internal_launch_k3_adjoint(l1_weight != 0.0f, head, rows, grid.x, grid.y, lds_bytes, stream, input, target,
+                                          scenes, xrow, eps, inv_count, loss_scale, fixed_scale, l1.sum_scale,
+                                          l1.grad_scale, l1.eps, grad_input, ws, loss_out, B, S, H, W);
+    else
+        launch_k3<false>(l1_weight != 0.0f, head, rows, grid, block, lds_bytes, st, input, target, scenes, xrow, eps,
+                         inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, B, S, H, W);
     return launch_status(who);
 }
 
@@ -1288,3 +1333,4 @@ int svbrdf_debug_check_arith(unsigned long long n, unsigned seed, float lo, floa
 }
 
 }  // extern "C"
+#endif  // SVBRDF_TU_MAIN
