@@ -26,7 +26,8 @@ int main(int argc, char **argv)
                 float *q = &m[(size_t)b * 12 * plane + p];
                 q[0 * plane] = nx * il; q[1 * plane] = ny * il; q[2 * plane] = nz * il;
                 const float r = urand();
-                for (int k = 0; k < 3; ++k) { q[(3 + k) * plane] = urand(); q[(6 + k) * plane] = r; q[(9 + k) * plane] = urand(); }
+                const bool untied = std::getenv("K3_UNTIED") != nullptr;      // independent roughness channels: three-lobe path
+                for (int k = 0; k < 3; ++k) { q[(3 + k) * plane] = urand(); q[(6 + k) * plane] = untied ? urand() : r; q[(9 + k) * plane] = urand(); }
             }
     }
     for (size_t i = 0; i < sc.size() / 9; ++i) {
