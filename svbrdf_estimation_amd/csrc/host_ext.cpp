@@ -305,7 +305,11 @@ struct FusedLoss : public torch::autograd::Function<FusedLoss> {
                     "so call forward again instead of retain_graph");
         ctx->saved_data["done"] = true;
         void *st = reinterpret_cast<void *>(ctx->saved_data["stream"].toInt());   // backward runs on the forward's stream
-        const auto scale = grad_out[0].detach().to(at::kFloat).reshape({1});
+        // the upstream gradient of the scalar loss, as a one-element fp32 device buffer (loss.backward() hands over
+        // exactly that: no ops needed)
+        const at::Tensor &g0 = grad_out[0];
+        const auto scale = (g0.scalar_type() == at::kFloat && g0.numel() == 1 && g0.is_contiguous())
+                               ? g0 : g0.detach().to(at::kFloat).reshape({1});
         // The buffers are MOVED out of the node: AccumulateGrad adopts a gradient it holds the only
         // reference to and clones it otherwise (measured: a 25 MB device copy, 7.4 us, per step).
         at::Tensor gi, gt;
