@@ -57,6 +57,16 @@ def parse_args():
                          "multi-rank control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-device", action="store_true",
                     help="every rank uses cuda:0 (plumbing tests only, with --backend gloo)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the steps are issued on, round-robin (step k runs entirely -- forward launch and "
+                         "backward -- on stream k mod N).  Steps are independent batches, so with N = 2 the ramp and tail "
+                         "of one step's kernel are filled by the next step's (DESIGN.md section 5)")
+    ap.add_argument("--rotate", type=int, default=1,
+                    help="distinct (input, target) batches visited round-robin by the steps; 6 x 50 MB exceeds the "
+                         "256 MiB Infinity Cache")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="multi-rank control flow only (rank launch, rendezvous, barrier, MAX over ranks, one JSON line "
+                         "with ranks_seen) without touching a GPU: what the CPU test suite runs with --backend gloo")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     ap.add_argument("--engine-threads", action="store_true",
                     help="keep PyTorch's multithreaded backward engine (default: run backward on the calling thread; "
@@ -183,14 +193,51 @@ def secondary_kernels(dev, H):
     return out
 
 
+def plumbing_only(args, rank, world):
+    """--plumbing-only: everything of the multi-rank protocol except the GPU work (CPU test of the launch path)."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    seen = 1
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seen = dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({"metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)", "value": None,
+                          "unit": "patches/s", "n_gpus": world, "ranks_seen": seen, "plumbing_only": True,
+                          "elapsed_max_over_ranks_s": float(t.item()),
+                          "launch": "self-spawned" if os.environ.get("SVBRDF_SELF_SPAWNED") else "external launcher"}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    from svbrdf_estimation_amd import launch
+    if args.gpus > 1 and not launch.launched_as_rank():
+        # started as ONE plain process (`python bench.py --gpus N`): become the parent of N fresh rank processes.
+        # Nothing has initialised the GPU runtime in this process and nothing will (see launch.py).
+        os.environ["SVBRDF_SELF_SPAWNED"] = "1"
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (or let bench.py spawn them: run it "
+                         "without a rank environment)" % (args.gpus, world))
+    if args.plumbing_only:
+        return plumbing_only(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if not args.share_device and torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d but only %d device(s) visible" % (world, torch.cuda.device_count()))
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -216,8 +263,10 @@ def main():
     B, H, S = args.batch, args.size, args.random_scenes + args.specular_scenes
     gen = torch.Generator().manual_seed(distributed.rank_seed(1234, rank))
     inp_h, tgt_h = synthetic_maps(gen, B, H), synthetic_maps(gen, B, H)
-    inp = inp_h.to(dev).requires_grad_(True)
-    tgt = tgt_h.to(dev)
+    batches = [(inp_h.to(dev).requires_grad_(True), tgt_h.to(dev))]
+    for _ in range(1, max(1, args.rotate)):
+        batches.append((synthetic_maps(gen, B, H).to(dev).requires_grad_(True), synthetic_maps(gen, B, H).to(dev)))
+    streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else None
     loss_fn = losses.RenderingLoss(renderers.LocalRenderer())
     loss_fn.random_configuration_count = args.random_scenes
     loss_fn.specular_configuration_count = args.specular_scenes
@@ -249,10 +298,19 @@ def main():
         raw_ev = [(p[0].cuda_event, p[1].cuda_event) if p is not None else None for p in ev]
         set_events = ext.set_timing_events
 
+    counter = {"k": 0}
+    nb, ns = len(batches), (len(streams) if streams else 0)
+    set_stream = torch.cuda.set_stream
+
     def step():
         i = state["i"]
+        k = counter["k"]
+        counter["k"] = k + 1
+        if ns:
+            set_stream(streams[k % ns])       # the whole step (launch, backward) is issued on this stream
         if raw_ev and 0 <= i < len(raw_ev) and raw_ev[i] is not None:
             set_events(raw_ev[i][0], raw_ev[i][1])
+        inp, tgt = batches[k % nb]
         inp.grad = None
         loss = loss_fn(inp, tgt)
         loss.backward()
@@ -260,6 +318,7 @@ def main():
 
     if not args.engine_threads:
         torch.autograd.set_multithreading_enabled(False)
+    torch.cuda.synchronize(dev)               # inputs were produced on the default stream
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:      # untimed, see --settle-ms
         for _ in range(64):
@@ -281,6 +340,8 @@ def main():
         barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    if ns:
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
     _native.set_launch_hook(None)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if nccl else "cpu")
@@ -320,6 +381,9 @@ def main():
         out = {
             "metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)",
             "value": patches / elapsed, "unit": "patches/s", "n_gpus": world,
+            "ranks_seen": dist.get_world_size() if dist is not None else 1,
+            "launch": "self-spawned" if os.environ.get("SVBRDF_SELF_SPAWNED") else
+                      ("external launcher" if world > 1 else "single process"),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -88,3 +88,69 @@ def test_ddp_training_harness_two_ranks_cpu(tmp_path):
     assert np.allclose(a, b) and np.isfinite(a).all()          # the reported loss is the global mean on every rank
     ck = torch.load(str(tmp_path / "ckpt.tar"), map_location="cpu", weights_only=False)
     assert ck["model_type"] == "single" and len(ck["model_state_dict"]) == 98
+
+
+# ---------------------------------------------------------------- row e: `--gpus N` starts its own N ranks
+def _clean_env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    return env
+
+
+def _json_lines(text):
+    import json
+    out = []
+    for line in text.splitlines():
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            out.append(json.loads(line))
+    return out
+
+
+def test_bench_gpus_n_spawns_n_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` exactly as the driver calls it (one plain process, no torchrun, no rank
+    environment): the parent must start 2 fresh rank processes, relay rank 0's single JSON line and report what
+    torch.distributed saw.  --plumbing-only keeps the GPU out of it (gloo rendezvous, barrier, MAX over ranks)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--plumbing-only"], env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    assert lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == 2 and lines[0]["launch"] == "self-spawned"
+    assert lines[0]["elapsed_max_over_ranks_s"] >= 0.02           # MAX over ranks: rank 1 sleeps 20 ms
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """a launcher environment whose WORLD_SIZE contradicts --gpus must be an error, not a silent 1-rank run"""
+    import subprocess
+    env = _clean_env()
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr and not _json_lines(r.stdout)
+
+
+def test_spawned_rank_failure_stops_the_others_and_fails_the_parent(tmp_path):
+    from svbrdf_estimation_amd import launch
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(7)\n"
+                      "time.sleep(60)\n")
+    import time
+    t0 = time.monotonic()
+    rc = launch.spawn_ranks(str(script), [], 3)
+    assert rc == 7 and time.monotonic() - t0 < 30          # ranks 0 and 2 were terminated, not waited for
+
+
+def test_train_gpus_n_spawns_n_ranks_cpu(tmp_path):
+    """train.py --gpus 2 as one plain process (CPU plumbing configuration: gloo, stock L1 loss)"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--gpus", "2", "--device", "cpu", "--loss", "l1",
+                        "--steps", "1", "--warmup", "0", "--batch", "1", "--workers", "0"], env=_clean_env(),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == 2

@@ -1,0 +1,103 @@
+// tools/k3_split_bench.cpp -- does overlapping K3 launches claim the ramp/tail of one launch?  Times, through the C ABI
+// (include/svbrdf_hip.h), config 2 (B=8, 256x256, S=9) as: one launch per step; the batch split over 2 / 4 streams with a
+// fork/join per step; the same without joins (upper bound); full-batch launches alternating on two free-running streams
+// (what two processes sharing the GPU do).  Not product code.
+//   hipcc -O2 -Iinclude tools/k3_split_bench.cpp -o tools/_build/k3_split_bench -Lsvbrdf_estimation_amd/lib -lsvbrdf_hip
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "svbrdf_hip.h"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+#define CA(x) do { int r_ = (x); if (r_ != 0) { std::printf("%s: rc %d %s\n", #x, r_, svbrdf_last_error()); return 1; } } while (0)
+static unsigned rng_state = 12345u;
+static float urand() { rng_state = rng_state * 1664525u + 1013904223u; return (float)(rng_state >> 8) * (1.0f / 16777216.0f); }
+static float grand() { float u = urand() + 1e-7f, v = urand(); return std::sqrt(-2.0f * std::log(u)) * std::cos(6.2831853f * v); }
+
+int main()
+{
+    const int B = std::getenv("K3_B") ? std::atoi(std::getenv("K3_B")) : 8, H = 256, W = 256, S = 9;
+    const int steps = std::getenv("K3_STEPS") ? std::atoi(std::getenv("K3_STEPS")) : 1000;
+    const size_t plane = (size_t)H * W, n = (size_t)B * 12 * plane;
+    std::vector<float> in(n), tg(n), sc((size_t)B * S * 9), xr(W);
+    for (int which = 0; which < 2; ++which) {
+        std::vector<float> &m = which ? tg : in;
+        for (int b = 0; b < B; ++b)
+            for (size_t p = 0; p < plane; ++p) {
+                float nx = 0.3f * grand(), ny = 0.3f * grand(), nz = 1.0f + std::fabs(0.3f * grand());
+                const float il = 1.0f / std::sqrt(nx * nx + ny * ny + nz * nz);
+                float *q = &m[(size_t)b * 12 * plane + p];
+                q[0 * plane] = nx * il; q[1 * plane] = ny * il; q[2 * plane] = nz * il;
+                const float r = urand();
+                for (int k = 0; k < 3; ++k) { q[(3 + k) * plane] = urand(); q[(6 + k) * plane] = r; q[(9 + k) * plane] = urand(); }
+            }
+    }
+    for (size_t i = 0; i < sc.size() / 9; ++i) {
+        float *q = &sc[i * 9];
+        const float r1 = std::sqrt(0.001f + 0.899f * urand()), ph = 6.2831853f * urand(), d = 0.8f + 2.0f * urand();
+        q[0] = r1 * std::cos(ph) * d; q[1] = r1 * std::sin(ph) * d; q[2] = std::sqrt(1 - r1 * r1) * d + 1e-3f;
+        const float r2 = std::sqrt(0.001f + 0.899f * urand()), p2 = 6.2831853f * urand(), d2 = 0.8f + 2.0f * urand();
+        q[3] = r2 * std::cos(p2) * d2; q[4] = r2 * std::sin(p2) * d2; q[5] = std::sqrt(1 - r2 * r2) * d2 + 1e-3f;
+        q[6] = q[7] = q[8] = 20.0f;
+    }
+    CA(svbrdf_make_xrow(xr.data(), W));
+    constexpr int NS = 4;
+    float *d_in, *d_tg, *d_xr, *d_grad, *d_loss; unsigned long long *d_ws;
+    const size_t wsb = svbrdf_rendering_loss_workspace_bytes(B, S, H, W);
+    CK(hipMalloc(&d_in, n * 4)); CK(hipMalloc(&d_tg, n * 4)); CK(hipMalloc(&d_grad, n * 4));
+    CK(hipMalloc(&d_xr, W * 4)); CK(hipMalloc(&d_loss, 4 * NS)); CK(hipMalloc(&d_ws, wsb * NS)); CK(hipMemset(d_ws, 0, wsb * NS));
+    CK(hipMemcpy(d_in, in.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_tg, tg.data(), n * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_xr, xr.data(), W * 4, hipMemcpyHostToDevice));
+    hipStream_t st[NS];
+    for (int i = 0; i < NS; ++i) CK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+    hipEvent_t fork_ev, join_ev[NS];
+    CK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+    for (int i = 0; i < NS; ++i) CK(hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming));
+
+    // part p of `parts` on stream s: items [p*B/parts, (p+1)*B/parts)
+    auto launch = [&](int p, int parts, int s) -> int {
+        const int b0 = p * B / parts, nb = (p + 1) * B / parts - b0;
+        return svbrdf_mixed_loss_fwd_bwd_host_scenes(d_in + (size_t)b0 * 12 * plane, d_tg + (size_t)b0 * 12 * plane,
+                                                     sc.data() + (size_t)b0 * S * 9, d_xr, 0.1f, 0.0f, 0.01f, d_loss + s,
+                                                     d_grad + (size_t)b0 * 12 * plane, (char *)d_ws + wsb * s, wsb, nb, S, H, W, st[s]);
+    };
+    struct Mode { const char *name; int parts; bool join; bool alternate; };
+    const Mode modes[] = {
+        {"one launch per step", 1, false, false},
+        {"2 halves on 2 streams, fork/join per step", 2, true, false},
+        {"4 quarters on 4 streams, fork/join per step", 4, true, false},
+        {"2 halves on 2 streams, free-running", 2, false, false},
+        {"full launches alternating on 2 free streams", 1, false, true},
+        {"2 halves on ONE stream", -2, false, false},
+    };
+    for (int round = 0; round < 3; ++round)
+        for (const Mode &m : modes) {
+            double best = 1e30;
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipDeviceSynchronize());
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int i = 0; i < steps; ++i) {
+                    if (m.parts < 0) {
+                        for (int p = 0; p < -m.parts; ++p) CA(launch(p, -m.parts, 0));
+                    } else if (m.alternate) {
+                        CA(launch(0, 1, i & 1));
+                    } else if (m.join) {
+                        CK(hipEventRecord(fork_ev, st[0]));
+                        for (int p = 1; p < m.parts; ++p) CK(hipStreamWaitEvent(st[p], fork_ev, 0));
+                        for (int p = 0; p < m.parts; ++p) CA(launch(p, m.parts, p));
+                        for (int p = 1; p < m.parts; ++p) { CK(hipEventRecord(join_ev[p], st[p])); CK(hipStreamWaitEvent(st[0], join_ev[p], 0)); }
+                    } else {
+                        for (int p = 0; p < m.parts; ++p) CA(launch(p, m.parts, p));
+                    }
+                }
+                CK(hipDeviceSynchronize());
+                const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / steps;
+                if (us < best) best = us;
+            }
+            std::printf("round %d  %-48s %7.2f us/step  %8.0f patches/s\n", round, m.name, best, B / (best * 1e-6));
+            std::fflush(stdout);
+        }
+    return 0;
+}

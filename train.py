@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """train.py -- data-parallel training harness around the rendering-loss engine.
 
-One process per GPU (torchrun), batch sharded by rank with a DistributedSampler, stock
+One process per GPU (started by torchrun, or by this script itself: ``--gpus N`` without a rank environment
+spawns N fresh rank processes before anything touches a GPU, svbrdf_estimation_amd/launch.py), batch sharded by rank with a DistributedSampler, stock
 DistributedDataParallel for the U-Net: its ~320 MB of fp32 gradients per step are all-reduced by
 RCCL over xGMI in buckets overlapped with the backward pass (backend "nccl" is RCCL on ROCm).  The
 rendering / mixed loss itself needs no collective: each rank evaluates it on its shard with its own
@@ -10,7 +11,8 @@ gradient.  What the reference's main.py:56-150 does on one GPU, in the reference
 batch -> (synthesise missing photos) -> model -> MixedLoss -> backward -> Adam(lr 1e-5).
 
   python train.py --steps 20                                   # 1 GPU, synthetic SVBRDFs, single-view
-  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py --batch 8 --steps 100
+  python train.py --gpus 8 --batch 8 --steps 100               # 8 GPUs: spawns its own 8 ranks (config 3: global batch 64)
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py --gpus 8 --batch 8 --steps 100
   python train.py --model multi --views 5 --batch 16           # BASELINE config 4
   python train.py --size 512 --random-scenes 11 --specular-scenes 21   # BASELINE config 5 (per GPU)
   python train.py --data /path/to/tiled_pngs --image-count 10  # Deschaintre tiled-PNG samples
@@ -32,6 +34,8 @@ import torch  # noqa: E402
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=0,
+                    help="ranks (one per GPU).  0: whatever the launcher's WORLD_SIZE says (1 without a launcher)")
     ap.add_argument("--data", default="synthetic", help="'synthetic' or a directory of tiled PNG samples")
     ap.add_argument("--image-count", type=int, default=10, help="photos stored per tiled PNG")
     ap.add_argument("--model", choices=("single", "multi"), default="single")
@@ -68,6 +72,9 @@ def run(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus and args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (or run train.py without a rank "
+                         "environment and let it spawn them)" % (args.gpus, world))
     on_gpu = args.device == "cuda"
     if on_gpu:
         assert torch.cuda.is_available(), "no ROCm device visible"
@@ -167,6 +174,7 @@ def run(args):
     first, last = distributed.global_mean(first).item(), distributed.global_mean(last).item()
     result = {"metric": "end-to-end training patches/s (U-Net + %s loss)" % args.loss,
               "value": world * args.batch * args.steps / elapsed, "unit": "patches/s", "n_gpus": world,
+              "ranks_seen": dist.get_world_size() if world > 1 else 1,
               "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps, "warmup": args.warmup,
               "loss_first_quarter": first, "loss_last_quarter": last,
               "config": {"model": args.model, "views": args.views, "size": args.size, "per_gpu_batch": args.batch,
@@ -182,5 +190,15 @@ def run(args):
     return result
 
 
+def main(argv=None):
+    args = parse_args(argv)
+    from svbrdf_estimation_amd import launch
+    if args.gpus > 1 and not launch.launched_as_rank():
+        # one plain process asked for N GPUs: become the parent of N fresh rank processes (no GPU call has
+        # happened in this process and none will)
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:] if argv is None else argv, args.gpus))
+    return run(args)
+
+
 if __name__ == "__main__":
-    run(parse_args())
+    main()
