@@ -85,6 +85,9 @@ SVBRDF_API size_t svbrdf_rendering_loss_workspace_bytes(int B, int S, int H, int
  *   loss_out[0] = mean_{b,s,c,i,j} | log(render(input)+eps) - log(render(target)+eps) |
  *   grad_input  = d loss / d input  (for upstream gradient 1.0), or NULL for
  *                 forward-only.
+ * A NaN or infinite value anywhere in `input` / `target` (or a radiance beyond any the
+ * renderer can produce) gives loss_out[0] = NaN, like the reference's clamp/log chain, and
+ * the scratch is still left zeroed for the next call.
  * `scenes` are the light/view samples the caller drew (losses.py:35).  `eps` (losses.py:45:
  * 0.1) must lie in [1e-9, 1e9] (SVBRDF_ERR_DIMS otherwise): the kernel derives the three
  * 1/(render+eps) of a pixel from one reciprocal of their product. */

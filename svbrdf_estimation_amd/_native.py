@@ -263,6 +263,10 @@ def rendering_loss(input, target, scenes, eps=0.1, want_grad=True, l1_weight=0.0
                 ws.data_ptr(), ws.numel() * 8, B, S, H, W, _stream(input.device))
         if hook is not None:
             hook("end")
+    if rc != 0:
+        # a failed launch may leave partial sums / arrival counts behind: the scratch contract ("every completed
+        # call leaves it zeroed") only covers completed calls, so restore it before reporting the error
+        ws.zero_()
     _check(rc, entry)
     return loss, grad
 

@@ -278,15 +278,17 @@ struct FusedLoss : public torch::autograd::Function<FusedLoss> {
                               g_state.workspace.data_ptr(), ws_bytes, B, S, H, W, st);
         if (g_state.ev_end) g_abi.ev_record(g_state.ev_end, st);
         g_state.ev_begin = g_state.ev_end = nullptr;
+        if (rc != 0) g_state.workspace.zero_();   // only completed calls leave the scratch zeroed (svbrdf_hip.h)
         check(rc, "svbrdf_mixed_loss_fwd_bwd");
         if (need_tg) {   // every term is |g(a) - g(b)|: the target's gradient is the same kernel, roles swapped
             grad_tg = at::empty_like(tg);
             auto loss2 = at::empty({1}, in.options());
-            check(kernel_tg(tg.data_ptr<float>(), in.data_ptr<float>(), scenes.data_ptr<float>(),
-                              g_state.xrow.data_ptr<float>(), (float)eps, (float)l1_weight, (float)eps_l1,
-                              loss2.data_ptr<float>(), grad_tg.data_ptr<float>(), g_state.workspace.data_ptr(),
-                              ws_bytes, B, S, H, W, st),
-                  "svbrdf_mixed_loss_fwd_bwd (target)");
+            const int rc2 = kernel_tg(tg.data_ptr<float>(), in.data_ptr<float>(), scenes.data_ptr<float>(),
+                                      g_state.xrow.data_ptr<float>(), (float)eps, (float)l1_weight, (float)eps_l1,
+                                      loss2.data_ptr<float>(), grad_tg.data_ptr<float>(), g_state.workspace.data_ptr(),
+                                      ws_bytes, B, S, H, W, st);
+            if (rc2 != 0) g_state.workspace.zero_();
+            check(rc2, "svbrdf_mixed_loss_fwd_bwd (target)");
         }
         ctx->saved_data["has_in"] = need_in;
         ctx->saved_data["has_tg"] = need_tg;

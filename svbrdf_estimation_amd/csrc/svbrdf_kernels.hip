@@ -625,6 +625,8 @@ __device__ __forceinline__ float wave_sum(float v)
 constexpr int kLossSlots = 64;                    // sharded accumulators (power of two)
 constexpr int kLossCountShift = 48;               // word = arrivals << 48 | fixed-point sum
 constexpr unsigned long long kLossSumMask = (1ULL << kLossCountShift) - 1;
+constexpr unsigned long long kLossTicketMask = 0xffffffffULL;   // ws[kLossSlots]: low half counts slot completions,
+constexpr unsigned long long kLossNonFiniteFlag = 1ULL << 32;   // bit 32 = some workgroup's partial sum was not finite
 
 // one (pixel, scene) of the fused loss: both shadings, log/L1, adjoint of the input shading
 template <int NL, bool WITH_GRAD>
@@ -905,6 +907,18 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         const MapK mi = prepare<WITH_GRAD>(in[0]), mt = prepare<false>(tg[0]);
         float x[1], y;
         pixel_coords<1>(xrow, pix, W, x, y);
+        {
+            // torch.clamp propagates NaN (renderers.py:48-52, 87), v_max_f32 returns the other operand: a NaN (or
+            // infinite) normal or roughness value would vanish in the clamps and leave a finite loss beside NaN
+            // gradients.  t - t is 0 for finite t and NaN otherwise; added to the pixel's x coordinate (already live
+            // through the scene loop: no extra register) it leaves finite maps untouched and makes every radiance of
+            // the pixel, hence the loss, NaN when such a value is NaN (as the reference's is) or infinite (where the
+            // reference gives NaN, inf or a clamped value depending on the sign: NaN is the safe report).  Diffuse and
+            // specular propagate through the shading arithmetic by themselves.
+            const float chk = (((in[0].n[0] + in[0].n[1]) + (in[0].n[2] + in[0].r[0])) + (in[0].r[1] + in[0].r[2])) +
+                              (((tg[0].n[0] + tg[0].n[1]) + (tg[0].n[2] + tg[0].r[0])) + (tg[0].r[1] + tg[0].r[2]));
+            x[0] += chk - chk;
+        }
         const float *__restrict__ scp = scenes + (size_t)b * S * 9;
         if (__all(tied))     // wave-uniform: every lane's input AND target roughness channels are tied
             lsum = loss_scene_loop<1, WITH_GRAD>(mi, mt, x[0], y, scp, sc_lds, S, eps, inv_count, acc);
@@ -937,13 +951,24 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         const unsigned nblocks = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
         const unsigned slot = bid & (kLossSlots - 1);
         const unsigned slot_blocks = (nblocks - slot + kLossSlots - 1) / kLossSlots;
-        const unsigned long long fixed = (unsigned long long)(t * fixed_scale + 0.5f);   // < 2^48 by choice of scale
+        // The scale keeps every legitimate partial sum below 2^47 (loss_impl).  A partial sum that is NaN, infinite
+        // or beyond that (NaN/inf maps, or radiances no renderer input can produce) must neither be cast (undefined
+        // for NaN/inf) nor reach the arrival count in the word's top bits: it contributes 0 and raises the sticky
+        // non-finite flag next to the ticket counter instead, and the finisher reports NaN -- as the reference's
+        // log/L1 chain would (isfinite(loss) guards keep working) -- and leaves the scratch zeroed as always.
+        const float scaled = fma_(t, fixed_scale, 0.5f);
+        const bool finite = scaled >= 0.0f && scaled < 140737488355328.0f;       // 2^47; false for NaN
+        const unsigned long long fixed = finite ? (unsigned long long)scaled : 0ULL;
+        if (!finite) {
+            atomicOr(&ws[kLossSlots], kLossNonFiniteFlag);
+            __threadfence();        // the flag is visible device-wide before this workgroup's arrival is
+        }
         // device-scope returning atomic, performed at the memory side: add + arrival count in one
         const unsigned long long old = atomicAdd(&ws[slot], (1ULL << kLossCountShift) | fixed);
         if ((unsigned)(old >> kLossCountShift) + 1 == slot_blocks) {
             const unsigned nslots = nblocks < (unsigned)kLossSlots ? nblocks : (unsigned)kLossSlots;
             const unsigned long long ticket = atomicAdd(&ws[kLossSlots], 1ULL);
-            if (ticket + 1 == nslots) finisher = 1;
+            if ((unsigned)(ticket & kLossTicketMask) + 1 == nslots) finisher = 1;
         }
     }
     __syncthreads();
@@ -956,8 +981,9 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if (threadIdx.x == 0) {
-            atomicExch(&ws[kLossSlots], 0ULL);
-            loss_out[0] = (float)((double)v * loss_scale);
+            __threadfence();
+            const unsigned long long tail = atomicExch(&ws[kLossSlots], 0ULL);
+            loss_out[0] = (tail & kLossNonFiniteFlag) ? __builtin_nanf("") : (float)((double)v * loss_scale);
         }
     }
 }
@@ -1004,6 +1030,15 @@ __global__ SVBRDF_K3_ATTRS void k_rendering_loss_inl([[maybe_unused]] const Scen
     rendering_loss_body<WITH_GRAD, WITH_L1, HEAD>(input, target, rows, xrow, eps, inv_count, loss_scale, fixed_scale,
                                                   l1, grad_input, ws, loss_out, S, H, W);
 }
+
+#if defined(SVBRDF_ISA_PROBE)
+// tests/test_isa_guard.py: dot3 alone, to check in the assembly that its products are not contracted into FMAs
+extern "C" __global__ void svbrdf_isa_probe_dot3(const float *__restrict__ a, float *__restrict__ o)
+{
+    o[threadIdx.x] = dot3(a[threadIdx.x], a[threadIdx.x + 64], a[threadIdx.x + 128], a[threadIdx.x + 192], a[threadIdx.x + 256],
+                          a[threadIdx.x + 320]);
+}
+#endif
 
 #if SVBRDF_TU_MAIN
 // data[i] *= *scale, skipped entirely (no memory traffic) when *scale == 1: lets the autograd

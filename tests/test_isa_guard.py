@@ -1,0 +1,109 @@
+"""Compile-time regression guard of the fused loss kernel (CPU test: hipcc cross-compiles gfx950 without a GPU).
+
+The last ~10 % of K3's speed comes from per-translation-unit LLVM scheduler options and from algebra that removed
+transcendentals; nothing at run time would notice a toolchain bump or an innocent edit undoing either.  This test
+compiles the adjoint translation unit to assembly with the Makefile's own flags and checks the headline kernel
+k_rendering_loss_inl<GRAD=1,L1=0,HEAD=0> instruction by instruction:
+
+  * target gfx950, 4 waves/SIMD (<= 128 VGPRs), no AGPRs
+  * tied-roughness scene loop: VALU count within the budget, exactly 13 transcendentals, no scratch traffic,
+    no IEEE-division expansion (v_div_*), no packed math (the build uses -fno-slp-vectorize on purpose)
+  * three-lobe (untied) scene loop: transcendental count, bounded scratch traffic
+  * numerics contract: the products of the exact dot products on the coords -> NH path are never contracted into
+    FMAs: every dot3 must appear as 3 v_mul + 2 v_add; checked on the stand-alone `svbrdf_isa_probe_dot3` kernel
+    and by counting the plain multiplies/adds of the loop against the FMA count.
+"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+CSRC = os.path.join(ROOT, "svbrdf_estimation_amd", "csrc")
+HEADLINE = "k_rendering_loss_inlILb1ELb0ELb0"
+
+# budgets: measured values of the shipped build + a small margin (tools/isa_stats.py prints the current ones)
+TIED_LOOP_VALU_MAX = 340
+TIED_LOOP_TRANS = 13
+UNTIED_LOOP_VALU_MAX = 520
+UNTIED_LOOP_TRANS = 25
+UNTIED_LOOP_SCRATCH_MAX = 24
+
+
+def _make_var(name):
+    out = subprocess.check_output(["make", "-s", "-C", CSRC, "print-" + name], text=True)
+    return out.strip().split()
+
+
+@pytest.fixture(scope="module")
+def adjoint_asm(tmp_path_factory):
+    d = tmp_path_factory.mktemp("isa")
+    out = str(d / "adjoint.s")
+    cmd = (_make_var("HIPCC") + _make_var("HIPFLAGS") + _make_var("SCHED_ADJOINT") +
+           ["-DSVBRDF_TU=1", "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "svbrdf_kernels.hip")])
+    cmd = [c.replace("../../include", os.path.join(ROOT, "include")) for c in cmd]
+    subprocess.check_call(cmd, cwd=CSRC, stderr=subprocess.DEVNULL)
+    with open(out) as f:
+        return f.read()
+
+
+def test_headline_kernel_resources(adjoint_asm):
+    import isa_stats
+    assert '.amdgcn_target "amdgcn-amd-amdhsa--gfx950"' in adjoint_asm
+    name, meta, whole, loops, ins, rng = isa_stats.analyse(adjoint_asm, HEADLINE)
+    assert int(meta["NumVgprs"]) <= 128 and int(meta["NumAgprs"]) == 0, meta
+    assert int(meta["Occupancy"]) >= 4, meta
+    assert whole["v_div"] == 0 and whole["v_pk"] == 0, whole
+    print("headline kernel: %s" % {k: meta[k] for k in ("NumVgprs", "TotalNumSgprs", "ScratchSize", "Occupancy")})
+
+
+def test_scene_loops_instruction_budget(adjoint_asm):
+    import isa_stats
+    name, meta, whole, loops, ins, rng = isa_stats.analyse(adjoint_asm, HEADLINE)
+    assert len(loops) == 2, "expected the three-lobe and the tied scene loop, found %d loops" % len(loops)
+    untied, tied = sorted(loops, key=lambda c: -c["valu"])
+    print("tied loop: %s" % tied)
+    print("untied loop: %s" % untied)
+    assert tied["trans"] == TIED_LOOP_TRANS, tied
+    assert tied["valu"] <= TIED_LOOP_VALU_MAX, tied
+    assert tied["scratch"] == 0 and tied["vmem"] == 0 and tied["lds"] == 0, tied
+    assert tied["v_div"] == 0 and tied["v_pk"] == 0, tied
+    assert untied["trans"] == UNTIED_LOOP_TRANS, untied
+    assert untied["valu"] <= UNTIED_LOOP_VALU_MAX, untied
+    assert untied["scratch"] <= UNTIED_LOOP_SCRATCH_MAX and untied["v_div"] == 0, untied
+
+
+def test_every_adjoint_variant_tied_loop_budget(adjoint_asm):
+    import isa_stats
+    names = [k for k in isa_stats.kernels(adjoint_asm) if "k_rendering_loss" in k]
+    assert len(names) == 8, names            # {by-value, device table} x {L1} x {HEAD}
+    for k in names:
+        _, meta, whole, loops, _, _ = isa_stats.analyse(adjoint_asm, k)
+        assert int(meta["NumVgprs"]) <= 128, (k, meta)
+        assert whole["v_div"] == 0, k
+        tied = min(loops, key=lambda c: c["valu"])
+        with_l1 = "Lb1ELb1E" in k           # <GRAD=1, L1=1, ...>: the L1 accumulators cost the loop up to two spill slots
+        assert tied["scratch"] <= (2 if with_l1 else 0), (k, tied)
+        assert tied["trans"] == TIED_LOOP_TRANS and tied["valu"] <= TIED_LOOP_VALU_MAX, (k, tied)
+
+
+def test_dot_products_are_not_contracted(tmp_path):
+    """numerics contract (svbrdf_kernels.hip header): dot3 = three separately rounded products summed (p0+p1)+p2.
+    The probe kernel is dot3 and nothing else; with the product build flags it must compile to 3 v_mul + 2 v_add
+    and no FMA (an -ffp-contract=fast toolchain default would fuse two of the products)."""
+    import isa_stats
+    src = tmp_path / "probe.hip"
+    src.write_text('#define SVBRDF_ISA_PROBE 1\n#include "%s"\n' % os.path.join(CSRC, "svbrdf_kernels.hip"))
+    out = str(tmp_path / "probe.s")
+    cmd = (_make_var("HIPCC") + _make_var("HIPFLAGS") + _make_var("SCHED_MAIN") +
+           ["-DSVBRDF_TU=0", "-S", "--cuda-device-only", "-o", out, str(src)])
+    cmd = [c.replace("../../include", os.path.join(ROOT, "include")) for c in cmd]
+    subprocess.check_call(cmd, cwd=CSRC, stderr=subprocess.DEVNULL)
+    _, _, whole, _, ins, _ = isa_stats.analyse(open(out).read(), "svbrdf_isa_probe_dot3")
+    mns = [mn for _, _, mn, _ in ins if mn and mn.startswith("v_") and not mn.startswith("v_mov")]
+    muls = [m for m in mns if m.startswith("v_mul_f32")]
+    adds = [m for m in mns if m.startswith("v_add_f32")]
+    assert len(muls) == 3 and len(adds) == 2 and whole["fma"] == 0, mns
