@@ -34,7 +34,6 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_VALU_PEAK_TFLOPS = 157.3   # ditto, packed-FMA vector peak
 FLOP_PER_PIXEL_SCENE = 573.0    # SURVEY.md 8d (div/sqrt/log/pow counted as 1)
-K3_CLOCK_GHZ = 2.11             # s_memtime / s_memrealtime inside K3 (tools/k3_cycles.py, profiles/r01_k3_cycles.txt)
 
 
 def parse_args():
@@ -57,17 +56,18 @@ def parse_args():
                          "multi-rank control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-device", action="store_true",
                     help="every rank uses cuda:0 (plumbing tests only, with --backend gloo)")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are issued on, round-robin (step k runs entirely -- forward launch and "
                          "backward -- on stream k mod N).  Steps are independent batches, so with N = 2 the ramp and tail "
                          "of one step's kernel are filled by the next step's (DESIGN.md section 5)")
-    ap.add_argument("--rotate", type=int, default=1,
+    ap.add_argument("--rotate", type=int, default=6,
                     help="distinct (input, target) batches visited round-robin by the steps; 6 x 50 MB exceeds the "
                          "256 MiB Infinity Cache")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="multi-rank control flow only (rank launch, rendezvous, barrier, MAX over ranks, one JSON line "
                          "with ranks_seen) without touching a GPU: what the CPU test suite runs with --backend gloo")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
+    ap.add_argument("--cpu-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--engine-threads", action="store_true",
                     help="keep PyTorch's multithreaded backward engine (default: run backward on the calling thread; "
                          "one process drives one GPU, the device-thread hop only adds wake-up latency)")
@@ -102,6 +102,37 @@ def _time_eager(threads, inp, tgt, table, budget_s, max_patches=400):
             return done / el, done, el
 
 
+def _all_cores_child(args, ncpu, limit_s=45.0):
+    """torch.set_num_threads(os.cpu_count()) in a child process with a hard time limit: on a 256-cpu host one eager
+    256x256 patch was measured to take minutes at 256 threads (oversubscription), so the figure is either the
+    rate or the statement that not even one patch finished within the limit."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", str(ncpu), "--size", str(args.size),
+           "--batch", "2", "--random-scenes", str(args.random_scenes), "--specular-scenes", str(args.specular_scenes)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s)
+        for line in r.stdout.splitlines():
+            if line.startswith("{"):
+                return json.loads(line)["patches_per_s"]
+        return "child failed: %s" % r.stderr[-200:]
+    except subprocess.TimeoutExpired:
+        return "< %.3f (no patch finished within %.0f s)" % (1.0 / limit_s, limit_s)
+
+
+def cpu_child(args):
+    """--cpu-child THREADS: times the eager port at that thread count on seeded inputs and prints one JSON line"""
+    from svbrdf_estimation_amd import losses, renderers
+    gen = torch.Generator().manual_seed(1234)
+    B = args.batch
+    inp, tgt = synthetic_maps(gen, B, args.size), synthetic_maps(gen, B, args.size)
+    fn = losses.RenderingLoss(renderers.LocalRenderer())
+    fn.random_configuration_count, fn.specular_configuration_count = args.random_scenes, args.specular_scenes
+    torch.manual_seed(313)
+    table = fn.sample_scene_table(B)
+    rate, done, el = _time_eager(args.cpu_child, inp, tgt, table, budget_s=5.0, max_patches=8)
+    print(json.dumps({"threads": args.cpu_child, "patches_per_s": rate, "patches": done, "seconds": el}), flush=True)
+
+
 def cpu_baseline(args, inp, tgt, table):
     """Eager-PyTorch port of the reference's algorithm on the host cores (bounded sample).
     Eager 256x256 elementwise ops do not scale to hundreds of threads, so a few thread
@@ -115,7 +146,11 @@ def cpu_baseline(args, inp, tgt, table):
     best = max(probe, key=probe.get)
     rate, done, el = _time_eager(best, inp, tgt, table, budget_s=args.cpu_seconds)
     one, _, _ = _time_eager(1, inp, tgt, table, budget_s=3.0, max_patches=4)
+    every = probe[ncpu] if ncpu in probe else _all_cores_child(args, ncpu)
     res = {"value": rate, "unit": "patches/s", "cores": best, "kind": "port",
+           "all_cores": {"threads": ncpu, "patches_per_s": every,
+                         "note": "torch.set_num_threads(os.cpu_count()) as BASELINE.md section 3 states it; eager "
+                                 "256x256 elementwise ops do not scale that far, so `value` is the best of a few counts"},
            "sample": "%d patches of %dx%d, S=%d, fwd+bwd, eager PyTorch restatement (oracle/eager_torch.py), "
                      "%.1f s, best of threads %s on a %d-cpu host" % (done, args.size, args.size, table.shape[1], el,
                                                                      cands, ncpu),
@@ -187,6 +222,36 @@ def secondary_kernels(dev, H):
         gb = 144.0 * Hk * Hk * B / (ms * 1e-3) / 1e9
         out[tag] = {"B": B, "H": Hk, "scenes": n_random + n_specular, "ms_per_launch": ms,
                     "patches_per_s": B / (ms * 1e-3), "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBPS}
+    def k3_module(tag, B, Hk, loss_fn, n_streams):
+        """whole steps through the module interface (host path, autograd), like the headline loop"""
+        g = torch.Generator().manual_seed(13)
+        sets = [(synthetic_maps(g, B, Hk).to(dev).requires_grad_(True), synthetic_maps(g, B, Hk).to(dev)) for _ in range(4)]
+        sts = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else None
+        torch.cuda.synchronize(dev)
+
+        def run(n):
+            for k in range(n):
+                if sts:
+                    torch.cuda.set_stream(sts[k % n_streams])
+                a, t = sets[k % 4]
+                a.grad = None
+                loss_fn(a, t).backward()
+        run(60)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run(300)
+        torch.cuda.synchronize(dev)
+        ms = 1e3 * (time.perf_counter() - t0) / 300
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+        gb = 144.0 * Hk * Hk * B / (ms * 1e-3) / 1e9
+        out[tag] = {"B": B, "H": Hk, "streams": n_streams, "ms_per_step": ms, "patches_per_s": B / (ms * 1e-3),
+                    "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBPS}
+    from svbrdf_estimation_amd import losses, renderers
+    mixed = losses.MixedLoss(renderers.LocalRenderer())
+    # BASELINE configs[3]: batch 16, mixed loss (the multi-view network's output has the same loss shapes); 144 scene
+    # rows exceed the kernel-argument route, so the table is uploaded (pinned ring)
+    k3_module("K3_config4_B16_mixed_loss", 16, H, mixed, 1)
+    k3_module("K3_config4_B16_mixed_loss_2streams", 16, H, mixed, 2)
     k3("K3_config2_roughness_U(0.2,1)", 8, H, 3, 6, rough_min=0.2)
     k3("K3_config2_untied_roughness", 8, H, 3, 6, tied=False)
     k3("K3_config5_512_32scenes", 8, 512, 11, 21)
@@ -221,6 +286,8 @@ def plumbing_only(args, rank, world):
 
 def main():
     args = parse_args()
+    if args.cpu_child:
+        return cpu_child(args)
     from svbrdf_estimation_amd import launch
     if args.gpus > 1 and not launch.launched_as_rank():
         # started as ONE plain process (`python bench.py --gpus N`): become the parent of N fresh rank processes.
@@ -354,56 +421,144 @@ def main():
     kernel_ms = sorted(p[0].elapsed_time(p[1]) for p in ev if p is not None)
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
 
+    # ---- untimed follow-up phases (same process, same tensors): the shader clock under this load, and the kernel alone
+    state["i"] = -1
+    clock_ghz, clock_note = None, "not measured"
+    try:
+        probe_stream = torch.cuda.Stream(dev)
+        probe_out = torch.zeros(2, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        _native.clock_probe(probe_out, ticks=300000, stream=probe_stream)     # 3 ms of the 100 MHz counter
+        t_probe = time.perf_counter()
+        while time.perf_counter() - t_probe < 4.5e-3:                         # the bench loop runs beside the probe
+            for _ in range(16):
+                step()
+        torch.cuda.synchronize(dev)
+        cyc, ticks = (int(v) for v in probe_out.tolist())
+        if ticks > 0:
+            clock_ghz = cyc / ticks * 0.1
+            clock_note = ("measured in this run: s_memtime / s_memrealtime of a one-wave probe kernel spinning %.1f ms on its own "
+                          "stream while the bench loop ran" % (ticks * 1e-5))
+    except Exception as e:  # pragma: no cover
+        clock_note = "probe failed: %r" % (e,)
+    # the kernel alone: one stream, one launch at a time, events around every 4th launch
+    if ns:
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+    alone_steps = max(80, min(args.steps, 1024))
+    alone_stride = max(1, min(16, alone_steps // 5))
+    ev_alone = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % alone_stride == 0 else None
+                for i in range(alone_steps)]
+    saved_ns, ns = ns, 0
+    if ext is not None:
+        for pair in ev_alone:
+            if pair is not None:
+                pair[0].record()
+                pair[1].record()
+        torch.cuda.synchronize(dev)
+    ev, raw_ev = ev_alone, ([(p[0].cuda_event, p[1].cuda_event) if p is not None else None for p in ev_alone]
+                            if ext is not None else [])
+    _native.set_launch_hook(hook)
+    t_alone = time.perf_counter()
+    for i in range(alone_steps):
+        state["i"] = i
+        step()
+    state["i"] = -1
+    torch.cuda.synchronize(dev)
+    alone_ms_per_step = 1e3 * (time.perf_counter() - t_alone) / alone_steps
+    _native.set_launch_hook(None)
+    ns = saved_ns
+    alone_ms = sorted(p[0].elapsed_time(p[1]) for p in ev_alone if p is not None)
+    alone_ms_avg = sum(alone_ms) / len(alone_ms)
+
     if rank == 0:
         patches = world * B * args.steps
+        ms_per_step = 1e3 * elapsed / args.steps
         alg_bytes = 144.0 * H * H * B                 # per launch: 36 planes x 4 B per patch
-        achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
-        traffic = valu_issue = None
+        # time one launch takes out of the timed region.  With one stream that is the launch's own duration; with N
+        # streams launches overlap (each takes longer, event-bracketed, than its share of the GPU), so the share is what
+        # the roofline is priced with: timed region / launches.  Host-bound gaps count against the kernel (conservative).
+        n_streams = max(1, saved_ns)
+        share_ms = ms_per_step if n_streams > 1 else kernel_ms_avg
+        achieved = alg_bytes / (share_ms * 1e-3) / 1e9
+        achieved_alone = alg_bytes / (alone_ms_avg * 1e-3) / 1e9
+        traffic = valu_issue = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "k3_hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                with open(tpath) as f:
-                    tj = json.load(f)
+                import hashlib
+                with open(tpath, "rb") as f:
+                    raw = f.read()
+                tj = json.loads(raw.decode())
                 if tj.get("B") == B and tj.get("H") == H and tj.get("S") == S:
                     traffic = tj.get("hbm_bytes_per_launch")
-                    if tj.get("valu_wave_instr_per_launch"):
+                    traffic_source = ("NOT measured in this run: PMC counters of the same kernel and shape recorded with "
+                                      "rocprofv3 --pmc by tools/collect_profiles.sh, replayed from profiles/k3_hbm_traffic.json "
+                                      "(sha1 %s, build %s)" % (hashlib.sha1(raw).hexdigest()[:12], tj.get("git_head", "?")))
+                    if tj.get("valu_wave_instr_per_launch") and clock_ghz:
                         # what actually bounds K3: wave64 VALU instructions issued (PMC SQ_INSTS_VALU of the same
                         # kernel, profiles/) against the SIMD-32 issue peak of one per 2 cycles per SIMD
-                        # (MI355X_MICROARCH.md), 1024 SIMDs, at the clock the chip holds under this kernel
-                        rate = tj["valu_wave_instr_per_launch"] / (kernel_ms_avg * 1e-3)
-                        peak = 1024 * K3_CLOCK_GHZ * 1e9 / 2.0
+                        # (MI355X_MICROARCH.md), 1024 SIMDs, at the clock the chip holds under this loop
+                        peak = 1024 * clock_ghz * 1e9 / 2.0
+                        rate = tj["valu_wave_instr_per_launch"] / (share_ms * 1e-3)
+                        rate_alone = tj["valu_wave_instr_per_launch"] / (alone_ms_avg * 1e-3)
                         valu_issue = {"wave_instr_per_launch": tj["valu_wave_instr_per_launch"],
                                       "of_which_transcendental": tj.get("trans_wave_instr_per_launch"),
+                                      "instr_count_source": traffic_source,
                                       "achieved_wave_instr_per_s": rate, "peak_wave_instr_per_s": peak,
-                                      "frac": rate / peak, "clock_GHz_under_kernel": K3_CLOCK_GHZ}
+                                      "frac": rate / peak, "frac_one_launch_alone": rate_alone / peak,
+                                      "clock_GHz_under_load": clock_ghz, "clock_source": clock_note}
             except Exception:
-                traffic = valu_issue = None
+                traffic = valu_issue = traffic_source = None
+        working_set = len(batches) * (2 * 12 + 12) * H * H * B * 4
         out = {
             "metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)",
             "value": patches / elapsed, "unit": "patches/s", "n_gpus": world,
             "ranks_seen": dist.get_world_size() if dist is not None else 1,
             "launch": "self-spawned" if os.environ.get("SVBRDF_SELF_SPAWNED") else
                       ("external launcher" if world > 1 else "single process"),
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic %dx%d 12-channel SVBRDF maps, %d light/view "
                                    "samples (%d random + %d specular), per-GPU batch %d, RenderingLoss fwd+bwd"
                                    % (H, H, S, args.random_scenes, args.specular_scenes, B),
                        "global_batch": world * B, "H": H, "W": H, "scenes": S,
-                       "parallelism": "batch-sharded x%d, no data-path collective" % world},
+                       "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                       "streams_per_gpu": n_streams,
+                       "step_issue": ("step k (launch + backward) is issued on HIP stream k mod %d: the steps are independent "
+                                      "batches, so one step's kernel fills the ramp and tail of the other's" % n_streams)
+                                     if n_streams > 1 else "every step on one stream",
+                       "distinct_batches": len(batches),
+                       "working_set_MiB": working_set / 2.0 ** 20,
+                       "working_set_note": "input + target + gradient of every batch visited round-robin; the Infinity "
+                                           "Cache holds 256 MiB"},
+            "single_stream": {"patches_per_s": B / (alone_ms_per_step * 1e-3), "ms_per_step": alone_ms_per_step,
+                              "kernel_ms_avg": alone_ms_avg, "kernel_ms_median": alone_ms[len(alone_ms) // 2],
+                              "kernel_launches_timed": len(alone_ms), "steps": alone_steps,
+                              "note": "same process, same tensors, right after the timed region: every step on one stream, "
+                                      "events around a sample of the launches (every 16th at the default step count) -- the duration rocprofv3 --kernel-trace reports for "
+                                      "`bench.py --streams 1`"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "achieved_definition": ("algorithmic bytes per launch / time per launch in the timed region "
+                                                 "(timed region / launches: launches on %d streams overlap)" % n_streams)
+                                                if n_streams > 1 else
+                                                "algorithmic bytes per launch / average event-bracketed launch duration",
+                         "time_per_launch_ms": share_ms,
+                         "one_launch_alone": {"achieved": achieved_alone, "frac": achieved_alone / HBM_PEAK_GBPS,
+                                              "kernel_ms_avg": alone_ms_avg},
                          "frac_of_measured_copy_peak": achieved / 6290.0,   # MI355X_MICROARCH.md: float4 copy
                          "kernel": "%s<GRAD=true,L1=false,HEAD=false> (single launch: both shadings, log/L1, adjoint, loss finalise)"
                                    % ("k_rendering_loss_inl" if B * S <= _native.host_scenes_max_rows() else "k_rendering_loss"),
                          "scene_table": "by value in the kernel-argument block (no H2D command)"
                                         if B * S <= _native.host_scenes_max_rows() else "pinned-ring upload",
-                         "kernel_limited_patches_per_s": B / (kernel_ms_avg * 1e-3),
+                         "kernel_limited_patches_per_s": B / (share_ms * 1e-3),
                          "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
+                         "kernel_ms_note": "event-bracketed duration of a launch in the timed region (with N > 1 streams it "
+                                           "overlaps its neighbours and exceeds time_per_launch_ms)",
                          "kernel_launches_timed": len(kernel_ms),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "valu_frac_of_fp32_peak": (FLOP_PER_PIXEL_SCENE * H * H * S * B / (kernel_ms_avg * 1e-3))
+                         "valu_frac_of_fp32_peak": (FLOP_PER_PIXEL_SCENE * H * H * S * B / (share_ms * 1e-3))
                                                    / (FP32_VALU_PEAK_TFLOPS * 1e12),
                          "valu_issue": valu_issue},
             "loss": mean_loss,

@@ -163,6 +163,12 @@ SVBRDF_API int svbrdf_scale_inplace(float *data, const float *scale_dev, size_t 
 SVBRDF_API int svbrdf_debug_check_arith(unsigned long long n, unsigned seed, float lo, float hi,
                                         unsigned long long *counts_dev, void *stream);
 
+/* Measurement aid: one wave spins for `ticks_100mhz` ticks of the chip's constant 100 MHz counter on `stream`
+ * and writes out_dev[0] = shader-clock cycles elapsed, out_dev[1] = 100 MHz ticks elapsed (two device uint64).
+ * cycles / ticks * 0.1 = the shader clock in GHz while whatever else is running runs (bench.py launches it on a
+ * stream of its own beside the fused loss: the clock the chip holds under that kernel). */
+SVBRDF_API int svbrdf_debug_clock_probe(unsigned long long *out_dev, unsigned long long ticks_100mhz, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -271,6 +271,21 @@ def rendering_loss(input, target, scenes, eps=0.1, want_grad=True, l1_weight=0.0
     return loss, grad
 
 
+def clock_probe(out, ticks=300000, stream=None):
+    """Measurement aid (svbrdf_debug_clock_probe): one wave spins for `ticks` ticks of the 100 MHz counter on
+    `stream` (a torch.cuda.Stream; default: the current one) and writes shader cycles / ticks into `out`
+    (device int64[2]).  cycles / ticks * 0.1 = shader clock in GHz under whatever else is running."""
+    if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.int64 and out.numel() >= 2):
+        raise TypeError("out must be a device int64 tensor of at least 2 elements")
+    lib = _load()
+    lib.svbrdf_debug_clock_probe.argtypes = [_fp, ctypes.c_ulonglong, _fp]
+    lib.svbrdf_debug_clock_probe.restype = ctypes.c_int
+    raw = stream.cuda_stream if stream is not None else _raw_stream(out.device)
+    with _on_device(out.device):
+        _check(lib.svbrdf_debug_clock_probe(out.data_ptr(), int(ticks), ctypes.c_void_p(raw)), "svbrdf_debug_clock_probe")
+    return out
+
+
 def host_scenes_max_rows():
     """largest B*S the *_host_scenes entry points take (the table rides in the 4 KB kernel-argument block)"""
     return int(_load().svbrdf_host_scenes_max_rows())

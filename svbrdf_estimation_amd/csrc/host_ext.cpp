@@ -14,7 +14,9 @@
 // Built by __graft_entry__.build() with torch.utils.cpp_extension (plain C++ extension).
 
 #include <torch/extension.h>
+#include <torch/csrc/autograd/functions/utils.h>
 #include <ATen/CPUGeneratorImpl.h>
+#include <ATen/core/DistributionsHelper.h>
 
 #include <dlfcn.h>
 
@@ -144,12 +146,20 @@ struct Sampler {
     {
         auto *gen = at::get_generator_or_default<at::CPUGeneratorImpl>(c10::nullopt, at::detail::getDefaultCPUGenerator());
         const int64_t raw_w = 4 * R + 2 * M;
-        float *raw_p = raw.data_ptr<float>(), *shift_p = shift_buf.data_ptr<float>();
+        float *raw_p = raw.data_ptr<float>(), *shift_p = shift_buf.data_ptr<float>(), *nrm_p = nrm.data_ptr<float>();
         for (int64_t i = 0; i < B; ++i) {
             draw_uniform(gen, raw_p + i * raw_w, raw_w, 1.0f, 0.0f);            // == raw_rows[i].uniform_(0, 1)
             if (M > 0) {
                 if (2 * M < 16) {
-                    nrm_rows[i].normal_(0.5, 0.75);     // sequential scalar path: == two M-element calls
+                    // == nrm_v[i].normal_(0.5, 0.75); nrm_l[i].normal_(0.5, 0.75): below 16 elements ATen's CPU kernel is
+                    // a serial loop of at::normal_distribution<double> (ATen/native/cpu/DistributionTemplates.h
+                    // normal_kernel; the Box-Muller pair is cached in the generator), called here without the dispatch
+                    std::lock_guard<std::mutex> lock(gen->mutex_);
+                    float *np_ = nrm_p + i * 2 * M;
+                    for (int64_t j = 0; j < 2 * M; ++j) {
+                        at::normal_distribution<double> normal(0.5, 0.75);
+                        np_[j] = static_cast<float>(normal(gen));
+                    }
                 } else {
                     nrm_v[i].normal_(0.5, 0.75);
                     nrm_l[i].normal_(0.5, 0.75);
@@ -251,24 +261,67 @@ struct State {
 } g_state;
 
 // ------------------------------------------------------------------------------------------
-// autograd node: the kernel has already produced d loss / d input for upstream gradient 1
+// autograd node: the kernel has already produced d loss / d input for upstream gradient 1.
+// A plain torch::autograd::Node (not the Function<> template: no AutogradContext, no saved_data dictionary of
+// IValues, no variable wrapping pass -- about 3 us less host time per step).
 // ------------------------------------------------------------------------------------------
-struct FusedLoss : public torch::autograd::Function<FusedLoss> {
-    static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &input, const at::Tensor &target,
-                              const at::Tensor &scenes, double eps, double l1_weight, double eps_l1, int64_t stream,
-                              bool head)
+struct FusedLossBackward : public torch::autograd::Node {
+    at::Tensor grad_in, grad_tg;     // moved out by apply()
+    bool has_in = false, has_tg = false, done = false;
+    void *stream = nullptr;          // backward is enqueued on the forward's stream
+
+    torch::autograd::variable_list apply(torch::autograd::variable_list &&grads) override
     {
-        const bool need_in = input.requires_grad(), need_tg = target.requires_grad();
-        TORCH_CHECK(!(head && need_tg), "the head-fused loss has no gradient w.r.t. the target maps");
-        // a host table goes into the kernel-argument block of the launch, a device table is read in place
-        const bool host_table = scenes.is_cpu();
-        const loss_fn_t kernel = host_table ? (head ? g_abi.head_host : g_abi.mixed_host) : (head ? g_abi.head : g_abi.mixed);
-        const loss_fn_t kernel_tg = host_table ? g_abi.mixed_host : g_abi.mixed;
+        TORCH_CHECK(!done, "the fused rendering loss was already back-propagated; its gradient buffer is scaled in place, "
+                           "so call forward again instead of retain_graph");
+        done = true;
+        // the upstream gradient of the scalar loss, as a one-element fp32 device buffer (loss.backward() hands over
+        // exactly that: no ops needed)
+        const at::Tensor &g0 = grads[0];
+        TORCH_CHECK(g0.defined(), "fused rendering loss: undefined upstream gradient");
+        const auto scale = (g0.scalar_type() == at::kFloat && g0.numel() == 1 && g0.is_contiguous())
+                               ? g0 : g0.detach().to(at::kFloat).reshape({1});
+        // The buffers are MOVED out of the node: AccumulateGrad adopts a gradient it holds the only
+        // reference to and clones it otherwise (measured: a 25 MB device copy, 7.4 us, per step).
+        torch::autograd::variable_list out(2);
+        if (has_in) {
+            check(g_abi.scale(grad_in.data_ptr<float>(), scale.data_ptr<float>(), (size_t)grad_in.numel(), stream), "svbrdf_scale_inplace");
+            out[0] = std::move(grad_in);
+        }
+        if (has_tg) {
+            check(g_abi.scale(grad_tg.data_ptr<float>(), scale.data_ptr<float>(), (size_t)grad_tg.numel(), stream), "svbrdf_scale_inplace");
+            out[1] = std::move(grad_tg);
+        }
+        return out;
+    }
+
+    void release_variables() override
+    {
+        grad_in.reset();
+        grad_tg.reset();
+    }
+
+    std::string name() const override { return "SvbrdfFusedLossBackward"; }
+};
+
+// launches the fused kernel(s) and returns the 0-dim loss with the node attached
+at::Tensor run_fused(const at::Tensor &input, const at::Tensor &target, const at::Tensor &scenes, double eps, double l1_weight,
+                     double eps_l1, int64_t stream, bool head)
+{
+    const bool grad_mode = at::GradMode::is_enabled();
+    const bool need_in = grad_mode && input.requires_grad(), need_tg = grad_mode && target.requires_grad();
+    TORCH_CHECK(!(head && need_tg), "the head-fused loss has no gradient w.r.t. the target maps");
+    // a host table goes into the kernel-argument block of the launch, a device table is read in place
+    const bool host_table = scenes.is_cpu();
+    const loss_fn_t kernel = host_table ? (head ? g_abi.head_host : g_abi.mixed_host) : (head ? g_abi.head : g_abi.mixed);
+    const loss_fn_t kernel_tg = host_table ? g_abi.mixed_host : g_abi.mixed;
+    at::Tensor loss, grad_in, grad_tg;
+    void *st = reinterpret_cast<void *>(stream);
+    {
+        at::AutoDispatchBelowADInplaceOrView below_autograd;    // plain buffers: nothing here is recorded
         const auto in = input.contiguous(), tg = target.contiguous();
         const int B = (int)in.size(0), S = (int)scenes.size(1), H = (int)in.size(2), W = (int)in.size(3);
-        auto loss = at::empty({1}, in.options());
-        at::Tensor grad_in, grad_tg;
-        void *st = reinterpret_cast<void *>(stream);
+        loss = at::empty({}, in.options());
         const size_t ws_bytes = (size_t)g_state.workspace.numel() * 8;
         if (need_in) grad_in = at::empty_like(in);
         if (g_state.ev_begin) g_abi.ev_record(g_state.ev_begin, st);
@@ -290,44 +343,19 @@ struct FusedLoss : public torch::autograd::Function<FusedLoss> {
             if (rc2 != 0) g_state.workspace.zero_();
             check(rc2, "svbrdf_mixed_loss_fwd_bwd (target)");
         }
-        ctx->saved_data["has_in"] = need_in;
-        ctx->saved_data["has_tg"] = need_tg;
-        if (need_in) ctx->saved_data["grad_in"] = grad_in;
-        if (need_tg) ctx->saved_data["grad_tg"] = grad_tg;
-        ctx->saved_data["stream"] = stream;
-        ctx->saved_data["done"] = false;
-        return loss.select(0, 0);   // 0-dim view (NB: view({}) would pick the view(ScalarType) overload)
     }
-
-    static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx,
-                                                   torch::autograd::variable_list grad_out)
-    {
-        TORCH_CHECK(!ctx->saved_data["done"].toBool(),
-                    "the fused rendering loss was already back-propagated; its gradient buffer is scaled in place, "
-                    "so call forward again instead of retain_graph");
-        ctx->saved_data["done"] = true;
-        void *st = reinterpret_cast<void *>(ctx->saved_data["stream"].toInt());   // backward runs on the forward's stream
-        // the upstream gradient of the scalar loss, as a one-element fp32 device buffer (loss.backward() hands over
-        // exactly that: no ops needed)
-        const at::Tensor &g0 = grad_out[0];
-        const auto scale = (g0.scalar_type() == at::kFloat && g0.numel() == 1 && g0.is_contiguous())
-                               ? g0 : g0.detach().to(at::kFloat).reshape({1});
-        // The buffers are MOVED out of the node: AccumulateGrad adopts a gradient it holds the only
-        // reference to and clones it otherwise (measured: a 25 MB device copy, 7.4 us, per step).
-        at::Tensor gi, gt;
-        if (ctx->saved_data["has_in"].toBool()) {
-            gi = std::move(ctx->saved_data["grad_in"]).toTensor();
-            ctx->saved_data.erase("grad_in");
-            check(g_abi.scale(gi.data_ptr<float>(), scale.data_ptr<float>(), (size_t)gi.numel(), st), "svbrdf_scale_inplace");
-        }
-        if (ctx->saved_data["has_tg"].toBool()) {
-            gt = std::move(ctx->saved_data["grad_tg"]).toTensor();
-            ctx->saved_data.erase("grad_tg");
-            check(g_abi.scale(gt.data_ptr<float>(), scale.data_ptr<float>(), (size_t)gt.numel(), st), "svbrdf_scale_inplace");
-        }
-        return {gi, gt, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    if (need_in || need_tg) {
+        auto node = std::shared_ptr<FusedLossBackward>(new FusedLossBackward(), torch::autograd::deleteNode);
+        node->set_next_edges(torch::autograd::collect_next_edges(input, target));
+        node->grad_in = std::move(grad_in);
+        node->grad_tg = std::move(grad_tg);
+        node->has_in = need_in;
+        node->has_tg = need_tg;
+        node->stream = st;
+        torch::autograd::set_history(loss, node);
     }
-};
+    return loss;
+}
 
 void ensure_device_state(const at::Tensor &input, int S, int64_t stream)
 {
@@ -383,13 +411,13 @@ at::Tensor fused_loss(const at::Tensor &input, const at::Tensor &target, int64_t
         if (!g_state.host_table.defined() || g_state.host_table.size(0) != B || g_state.host_table.size(1) != S)
             g_state.host_table = at::empty({B, S, 9}, at::TensorOptions().dtype(at::kFloat));
         g_state.sampler.sample_into(g_state.host_table.data_ptr<float>());
-        return FusedLoss::apply(input, target, g_state.host_table, eps, l1_weight, eps_l1, stream, head);
+        return run_fused(input, target, g_state.host_table, eps, l1_weight, eps_l1, stream, head);
     }
     int slot = 0;
     auto pinned = g_state.ring.acquire(B * S * 9, slot);
     g_state.sampler.sample_into(pinned.data_ptr<float>());           // drawn straight into the upload slot
     const auto scenes = g_state.ring.submit(pinned, slot, {B, S, 9}, input.device(), reinterpret_cast<void *>(stream));
-    return FusedLoss::apply(input, target, scenes, eps, l1_weight, eps_l1, stream, head);
+    return run_fused(input, target, scenes, eps, l1_weight, eps_l1, stream, head);
 }
 
 // same with caller-provided scenes ([B,S,9] on the device, or on the host if B*S <= svbrdf_host_scenes_max_rows())
@@ -404,7 +432,7 @@ at::Tensor fused_loss_with_scenes(const at::Tensor &input, const at::Tensor &tar
                 "a host scene table may hold at most ", g_abi.host_rows, " rows; upload larger ones first");
     std::lock_guard<std::mutex> lock(g_state.mu);
     ensure_device_state(input, (int)scenes.size(1), stream);
-    return FusedLoss::apply(input, target, scenes.contiguous(), eps, l1_weight, eps_l1, stream, head);
+    return run_fused(input, target, scenes.contiguous(), eps, l1_weight, eps_l1, stream, head);
 }
 
 // the sampler alone (host tensor) -- used by the bit-exactness tests

@@ -1084,6 +1084,26 @@ __global__ __launch_bounds__(kThreads) void k_check_arith(unsigned long long n, 
 }
 
 // ------------------------------------------------------------------------------------------
+// measurement aid: the shader clock the chip holds while other kernels run.  One wave spins for `ticks` ticks of
+// the constant 100 MHz counter (s_memrealtime) and reports how many shader cycles (s_memtime) went by: launched
+// on a stream of its own beside the fused loss it reads the clock under THAT load (DVFS lowers it under VALU-dense
+// kernels); one wave on one SIMD does not disturb the measured kernels.  out[0] = shader cycles, out[1] = ticks.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *__restrict__ out, unsigned long long ticks)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = wall_clock64(), c0 = clock64();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        r1 = wall_clock64();
+    }
+    const unsigned long long c1 = clock64();
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 
@@ -1365,6 +1385,14 @@ int svbrdf_debug_check_arith(unsigned long long n, unsigned seed, float lo, floa
     hipLaunchKernelGGL(k_check_arith, dim3(2048), dim3(kThreads), 0, static_cast<hipStream_t>(stream), n, seed, lo, hi,
                        counts_dev);
     return launch_status("check_arith launch");
+}
+
+int svbrdf_debug_clock_probe(unsigned long long *out_dev, unsigned long long ticks_100mhz, void *stream)
+{
+    if (!out_dev) return fail(SVBRDF_ERR_NULL, "clock_probe: null pointer");
+    if (ticks_100mhz == 0 || ticks_100mhz > 100000000ULL) return fail(SVBRDF_ERR_DIMS, "clock_probe: 0 < ticks <= 1e8 (1 s)");
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), out_dev, ticks_100mhz);
+    return launch_status("clock_probe launch");
 }
 
 }  // extern "C"

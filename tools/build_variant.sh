@@ -1,0 +1,17 @@
+#!/bin/bash
+# Builds an experiment variant of libsvbrdf_hip.so into tools/_build/libsvbrdf_<tag>.so with extra flags for both
+# translation units (e.g. -DSVBRDF_X=1) and optional overrides SCHED_MAIN=... SCHED_ADJOINT=... in the environment.
+#   bash tools/build_variant.sh <tag> [extra compiler flags...]
+set -e
+tag=$1; shift
+cd "$(dirname "$0")/../svbrdf_estimation_amd/csrc"
+out=../../tools/_build
+mkdir -p $out/obj_$tag
+F="-O3 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -std=c++17 -fvisibility=hidden -I../../include $*"
+SM=${SCHED_MAIN:--mllvm -misched-postra-direction=bottomup}
+SA=${SCHED_ADJOINT:--mllvm -enable-post-misched=0 -mllvm -amdgpu-sched-strategy=max-memory-clause}
+/opt/rocm/bin/hipcc $F $SM -DSVBRDF_TU=0 -c -o $out/obj_$tag/main.o svbrdf_kernels.hip &
+/opt/rocm/bin/hipcc $F $SA -DSVBRDF_TU=1 -c -o $out/obj_$tag/adj.o svbrdf_kernels.hip &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o $out/libsvbrdf_$tag.so $out/obj_$tag/main.o $out/obj_$tag/adj.o
+echo built $out/libsvbrdf_$tag.so

@@ -2,14 +2,26 @@
 // (include/svbrdf_hip.h), config 2 (B=8, 256x256, S=9) as: one launch per step; the batch split over 2 / 4 streams with a
 // fork/join per step; the same without joins (upper bound); full-batch launches alternating on two free-running streams
 // (what two processes sharing the GPU do).  Not product code.
-//   hipcc -O2 -Iinclude tools/k3_split_bench.cpp -o tools/_build/k3_split_bench -Lsvbrdf_estimation_amd/lib -lsvbrdf_hip
+//   hipcc -O2 --offload-arch=gfx950 -Iinclude tools/k3_split_bench.cpp -o tools/_build/k3_split_bench -ldl
+//   K3_LIB=<path of a libsvbrdf_hip.so build> selects the library (default: the in-tree one); K3_MODES=0,3 selects modes
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <dlfcn.h>
+#include <string>
 #include "svbrdf_hip.h"
+// the library under test is chosen at run time (same-box A/B of builds): bind the four entry points used by name
+static decltype(&svbrdf_make_xrow) p_make_xrow;
+static decltype(&svbrdf_rendering_loss_workspace_bytes) p_ws_bytes;
+static decltype(&svbrdf_mixed_loss_fwd_bwd_host_scenes) p_loss;
+static decltype(&svbrdf_last_error) p_last_error;
+#define svbrdf_make_xrow p_make_xrow
+#define svbrdf_rendering_loss_workspace_bytes p_ws_bytes
+#define svbrdf_mixed_loss_fwd_bwd_host_scenes p_loss
+#define svbrdf_last_error p_last_error
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 #define CA(x) do { int r_ = (x); if (r_ != 0) { std::printf("%s: rc %d %s\n", #x, r_, svbrdf_last_error()); return 1; } } while (0)
 static unsigned rng_state = 12345u;
@@ -18,6 +30,17 @@ static float grand() { float u = urand() + 1e-7f, v = urand(); return std::sqrt(
 
 int main()
 {
+    const char *libpath = std::getenv("K3_LIB") ? std::getenv("K3_LIB") : "svbrdf_estimation_amd/lib/libsvbrdf_hip.so";
+    void *h = dlopen(libpath, RTLD_NOW);
+    if (!h) { std::printf("dlopen %s: %s\n", libpath, dlerror()); return 1; }
+    p_make_xrow = (decltype(p_make_xrow))dlsym(h, "svbrdf_make_xrow");
+    p_ws_bytes = (decltype(p_ws_bytes))dlsym(h, "svbrdf_rendering_loss_workspace_bytes");
+    p_loss = (decltype(p_loss))dlsym(h, "svbrdf_mixed_loss_fwd_bwd_host_scenes");
+    p_last_error = (decltype(p_last_error))dlsym(h, "svbrdf_last_error");
+    if (!p_make_xrow || !p_ws_bytes || !p_loss || !p_last_error) { std::printf("missing symbols in %s\n", libpath); return 1; }
+    const std::string only = std::getenv("K3_MODES") ? std::getenv("K3_MODES") : "";
+    const float l1w = std::getenv("K3_L1") ? (float)std::atof(std::getenv("K3_L1")) : 0.0f;
+    const bool untied = std::getenv("K3_UNTIED") != nullptr;
     const int B = std::getenv("K3_B") ? std::atoi(std::getenv("K3_B")) : 8, H = 256, W = 256, S = 9;
     const int steps = std::getenv("K3_STEPS") ? std::atoi(std::getenv("K3_STEPS")) : 1000;
     const size_t plane = (size_t)H * W, n = (size_t)B * 12 * plane;
@@ -31,7 +54,7 @@ int main()
                 float *q = &m[(size_t)b * 12 * plane + p];
                 q[0 * plane] = nx * il; q[1 * plane] = ny * il; q[2 * plane] = nz * il;
                 const float r = urand();
-                for (int k = 0; k < 3; ++k) { q[(3 + k) * plane] = urand(); q[(6 + k) * plane] = r; q[(9 + k) * plane] = urand(); }
+                for (int k = 0; k < 3; ++k) { q[(3 + k) * plane] = urand(); q[(6 + k) * plane] = untied ? urand() : r; q[(9 + k) * plane] = urand(); }
             }
     }
     for (size_t i = 0; i < sc.size() / 9; ++i) {
@@ -60,7 +83,7 @@ int main()
     auto launch = [&](int p, int parts, int s) -> int {
         const int b0 = p * B / parts, nb = (p + 1) * B / parts - b0;
         return svbrdf_mixed_loss_fwd_bwd_host_scenes(d_in + (size_t)b0 * 12 * plane, d_tg + (size_t)b0 * 12 * plane,
-                                                     sc.data() + (size_t)b0 * S * 9, d_xr, 0.1f, 0.0f, 0.01f, d_loss + s,
+                                                     sc.data() + (size_t)b0 * S * 9, d_xr, 0.1f, l1w, 0.01f, d_loss + s,
                                                      d_grad + (size_t)b0 * 12 * plane, (char *)d_ws + wsb * s, wsb, nb, S, H, W, st[s]);
     };
     struct Mode { const char *name; int parts; bool join; bool alternate; };
@@ -72,8 +95,10 @@ int main()
         {"full launches alternating on 2 free streams", 1, false, true},
         {"2 halves on ONE stream", -2, false, false},
     };
-    for (int round = 0; round < 3; ++round)
+    const int rounds = std::getenv("K3_ROUNDS") ? std::atoi(std::getenv("K3_ROUNDS")) : 3;
+    for (int round = 0; round < rounds; ++round)
         for (const Mode &m : modes) {
+            if (!only.empty() && only.find((char)('0' + (&m - modes))) == std::string::npos) continue;
             double best = 1e30;
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipDeviceSynchronize());
@@ -96,7 +121,9 @@ int main()
                 const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / steps;
                 if (us < best) best = us;
             }
-            std::printf("round %d  %-48s %7.2f us/step  %8.0f patches/s\n", round, m.name, best, B / (best * 1e-6));
+            float lossv = 0.0f;
+            CK(hipMemcpy(&lossv, d_loss, 4, hipMemcpyDeviceToHost));
+            std::printf("round %d  %-48s %7.2f us/step  %8.0f patches/s   loss %.7f\n", round, m.name, best, B / (best * 1e-6), lossv);
             std::fflush(stdout);
         }
     return 0;
