@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SVBRDF_ABI_VERSION 2
+#define SVBRDF_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define SVBRDF_API __attribute__((visibility("default")))
@@ -162,6 +162,14 @@ SVBRDF_API int svbrdf_scale_inplace(float *data, const float *scale_dev, size_t 
  * IEEE-correct a / sqrtf(x) to counts_dev[0] and from sqrtf(x) to counts_dev[1].  counts_dev: two zero-initialised device uint64. */
 SVBRDF_API int svbrdf_debug_check_arith(unsigned long long n, unsigned seed, float lo, float hi,
                                         unsigned long long *counts_dev, void *stream);
+
+/* K4 -- replaces SvbrdfDataset.mix (dataset.py:142-160), the material-mixing augmentation, for a whole batch:
+ *   out[b] = mix(svbrdf0[b], svbrdf1[b], alpha[b])   all [B,12,H,W] device, alpha [B] device (the reference draws
+ *   it per sample from U(0.1, 0.9), dataset.py:144).  Normals are projected to z = 1 (n / max(0.01, n.z)), blended
+ *   with weights alpha and fp32(1 - alpha) and renormalised; diffuse, roughness and specular are blended.  Same
+ *   operation order and roundings as the reference.  H and W are independent here.  `out` may not alias the inputs. */
+SVBRDF_API int svbrdf_mix_materials(const float *svbrdf0, const float *svbrdf1, const float *alpha, float *out,
+                                    int B, int H, int W, void *stream);
 
 /* Measurement aid: one wave spins for `ticks_100mhz` ticks of the chip's constant 100 MHz counter on `stream`
  * and writes out_dev[0] = shader-clock cycles elapsed, out_dev[1] = 100 MHz ticks elapsed (two device uint64).

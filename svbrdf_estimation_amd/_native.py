@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SVBRDF_HIP_LIB: load another build of the same ABI (ablation/experiment builds of tools/); default in-tree
 _SO = os.environ.get("SVBRDF_HIP_LIB") or os.path.join(_HERE, "lib", "libsvbrdf_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lock = threading.Lock()
 _lib = None
@@ -269,6 +269,29 @@ def rendering_loss(input, target, scenes, eps=0.1, want_grad=True, l1_weight=0.0
         ws.zero_()
     _check(rc, entry)
     return loss, grad
+
+
+def mix_materials(svbrdf0, svbrdf1, alpha):
+    """K4: out[b] = mix(svbrdf0[b], svbrdf1[b], alpha[b]) (dataset.py:142-160) for [B,12,H,W] device tensors and a
+    [B] device tensor of blend weights."""
+    for t, name in ((svbrdf0, "svbrdf0"), (svbrdf1, "svbrdf1"), (alpha, "alpha")):
+        _require_device_f32(t, name)
+    if svbrdf0.dim() != 4 or svbrdf0.shape[1] != 12 or svbrdf0.shape != svbrdf1.shape:
+        raise ValueError("svbrdf0 and svbrdf1 must both be [B,12,H,W]")
+    B, _, H, W = svbrdf0.shape
+    if alpha.numel() != B:
+        raise ValueError("alpha must hold one weight per batch item")
+    if svbrdf1.device != svbrdf0.device or alpha.device != svbrdf0.device:
+        raise ValueError("svbrdf0, svbrdf1 and alpha must be on the same device")
+    a, b, w = svbrdf0.contiguous(), svbrdf1.contiguous(), alpha.contiguous().view(-1)
+    out = torch.empty_like(a)
+    lib = _load()
+    lib.svbrdf_mix_materials.argtypes = [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]
+    lib.svbrdf_mix_materials.restype = ctypes.c_int
+    with _on_device(a.device):
+        _check(lib.svbrdf_mix_materials(a.data_ptr(), b.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W,
+                                        _stream(a.device)), "svbrdf_mix_materials")
+    return out
 
 
 def clock_probe(out, ticks=300000, stream=None):

@@ -258,7 +258,11 @@ struct State {
     at::Tensor workspace, xrow;      // the ones selected for the call in flight (under `mu`)
     at::Tensor host_table;           // [B,S,9] sampler target of the by-value route (consumed inside the call)
     int device = -1;
-} g_state;
+};
+// Deliberately never destroyed: the state owns device tensors, pinned host slots and events, and a static
+// destructor would release them AFTER the HIP runtime has shut down at interpreter exit (observed: a process that
+// had used the pinned upload ring printed its result and then hung in teardown).
+State &g_state = *new State();
 
 // ------------------------------------------------------------------------------------------
 // autograd node: the kernel has already produced d loss / d input for upstream gradient 1.

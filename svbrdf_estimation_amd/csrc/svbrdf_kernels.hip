@@ -1084,6 +1084,53 @@ __global__ __launch_bounds__(kThreads) void k_check_arith(unsigned long long n, 
 }
 
 // ------------------------------------------------------------------------------------------
+// K4: material mixing (dataset.py:142-160 SvbrdfDataset.mix), one pass over two SVBRDFs:
+//   normals projected to z = 1 (n / max(0.01, n.z)), blended, renormalised; diffuse / roughness / specular blended;
+//   weights alpha and fp32(1 - alpha) per batch item.  HBM-bound (24 planes in, 12 out = 144 B per pixel, ~40 flop).
+// Operation order and roundings are the reference's: every product rounded on its own (-ffp-contract=off), the
+// squared length summed (p0 + p1) + p2 like torch.sum over the channel axis, IEEE division and square root.
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void k_mix_materials(const float *__restrict__ m0, const float *__restrict__ m1,
+                                                            const float *__restrict__ alpha, float *__restrict__ out,
+                                                            size_t plane)
+{
+    const size_t pix = ((size_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
+    const int b = blockIdx.y;
+    if (pix >= plane) return;
+    const float a = alpha[b], oma = 1.0f - a;
+    const float *__restrict__ p0 = m0 + (size_t)b * 12 * plane + pix;
+    const float *__restrict__ p1 = m1 + (size_t)b * 12 * plane + pix;
+    float *__restrict__ po = out + (size_t)b * 12 * plane + pix;
+    float n0[3][VEC], n1[3][VEC], nm[3][VEC];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        load_vec<VEC, true>(p0 + (size_t)k * plane, n0[k]);
+        load_vec<VEC, true>(p1 + (size_t)k * plane, n1[k]);
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const float z0 = fmaxf(0.01f, n0[2][v]), z1 = fmaxf(0.01f, n1[2][v]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) nm[k][v] = a * (n0[k][v] / z0) + oma * (n1[k][v] / z1);
+        const float len = sqrtf((nm[0][v] * nm[0][v] + nm[1][v] * nm[1][v]) + nm[2][v] * nm[2][v]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) nm[k][v] = nm[k][v] / len;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) store_vec<VEC, true>(po + (size_t)k * plane, nm[k]);
+#pragma unroll
+    for (int k = 3; k < 12; ++k) {
+        float x0[VEC], x1[VEC], y[VEC];
+        load_vec<VEC, true>(p0 + (size_t)k * plane, x0);
+        load_vec<VEC, true>(p1 + (size_t)k * plane, x1);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) y[v] = a * x0[v] + oma * x1[v];
+        store_vec<VEC, true>(po + (size_t)k * plane, y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // measurement aid: the shader clock the chip holds while other kernels run.  One wave spins for `ticks` ticks of
 // the constant 100 MHz counter (s_memrealtime) and reports how many shader cycles (s_memtime) went by: launched
 // on a stream of its own beside the fused loss it reads the clock under THAT load (DVFS lowers it under VALU-dense
@@ -1385,6 +1432,25 @@ int svbrdf_debug_check_arith(unsigned long long n, unsigned seed, float lo, floa
     hipLaunchKernelGGL(k_check_arith, dim3(2048), dim3(kThreads), 0, static_cast<hipStream_t>(stream), n, seed, lo, hi,
                        counts_dev);
     return launch_status("check_arith launch");
+}
+
+int svbrdf_mix_materials(const float *svbrdf0, const float *svbrdf1, const float *alpha, float *out, int B, int H, int W,
+                         void *stream)
+{
+    if (!svbrdf0 || !svbrdf1 || !alpha || !out) return fail(SVBRDF_ERR_NULL, "mix_materials: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || B > 65535 || (long long)H * W > (1LL << 30))
+        return fail(SVBRDF_ERR_DIMS, "mix_materials: bad dimensions");
+    if (!aligned(svbrdf0, 4) || !aligned(svbrdf1, 4) || !aligned(alpha, 4) || !aligned(out, 4))
+        return fail(SVBRDF_ERR_ALIGN, "mix_materials: pointers must be 4-byte aligned");
+    const size_t plane = (size_t)H * W;
+    int vec = 4;            // whole planes are contiguous here: the vector width only needs H*W and the bases to agree
+    while (vec > 1 && !((plane % vec) == 0 && aligned(svbrdf0, 4 * vec) && aligned(svbrdf1, 4 * vec) && aligned(out, 4 * vec))) vec >>= 1;
+    const dim3 grid((unsigned)((plane + (size_t)kThreads * vec - 1) / ((size_t)kThreads * vec)), (unsigned)B, 1), block(kThreads);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (vec == 4) hipLaunchKernelGGL(k_mix_materials<4>, grid, block, 0, st, svbrdf0, svbrdf1, alpha, out, plane);
+    else if (vec == 2) hipLaunchKernelGGL(k_mix_materials<2>, grid, block, 0, st, svbrdf0, svbrdf1, alpha, out, plane);
+    else hipLaunchKernelGGL(k_mix_materials<1>, grid, block, 0, st, svbrdf0, svbrdf1, alpha, out, plane);
+    return launch_status("mix_materials launch");
 }
 
 int svbrdf_debug_clock_probe(unsigned long long *out_dev, unsigned long long ticks_100mhz, void *stream)

@@ -81,3 +81,25 @@ def render_inputs(svbrdf, count, use_augmentation=True, noise="device"):
         out = out + torch.randn_like(out) * stds.view(B, count, 1, 1, 1)
     out = out.clamp_(0.0, 1.0)
     return out[0] if single else out
+
+
+def draw_mix_alpha():
+    """the blend weight of one mixed sample, dataset.py:144: U(0.1, 0.9) from torch's global CPU generator"""
+    return torch.empty(1).uniform_(0.1, 0.9)
+
+
+def mix_materials(svbrdf_0, svbrdf_1, alpha=None):
+    """``SvbrdfDataset.mix`` (dataset.py:142-160) on the GPU (kernel K4): blend two materials -- normals projected
+    to z = 1, blended and renormalised; diffuse, roughness, specular blended -- with weight ``alpha`` (one value,
+    or one per batch item; drawn like the reference's when None).  [12,H,W] or [B,12,H,W] device tensors."""
+    single = svbrdf_0.dim() == 3
+    a = svbrdf_0.unsqueeze(0) if single else svbrdf_0
+    b = svbrdf_1.unsqueeze(0) if single else svbrdf_1
+    B = a.shape[0]
+    if alpha is None:
+        alpha = torch.cat([draw_mix_alpha() for _ in range(B)])
+    alpha = torch.as_tensor(alpha, dtype=torch.float32).reshape(-1)
+    if alpha.numel() == 1 and B > 1:
+        alpha = alpha.expand(B)
+    out = _native.mix_materials(a, b, alpha.to(a.device, non_blocking=True).contiguous())
+    return out[0] if single else out

@@ -38,27 +38,108 @@ def write_tiled_png(path, photos, svbrdf):
     Image.fromarray(np.uint8(np.round(row * 255.0))).save(path)
 
 
-class TiledPngDataset(torch.utils.data.Dataset):
-    """{'inputs': stored photos (gamma-decoded unless linear) [n,3,S,S], 'svbrdf': [12,S,S]}; missing photos
-    are added later on the GPU by ``complete_inputs``."""
+def _crop_square(t, anchor, size):
+    """utils.crop_square of the reference (utils.py:15-29) for one anchor: rows anchor[0].., columns anchor[1].."""
+    return t[..., anchor[0]:anchor[0] + size, anchor[1]:anchor[1] + size]
 
-    def __init__(self, directory, image_size=256, image_count=10, used_image_count=1, is_linear=False):
+
+class TiledPngDataset(torch.utils.data.Dataset):
+    """The reference's ``SvbrdfDataset`` (dataset.py:11-140), same constructor meaning:
+
+    ``scale_mode``  'crop' -- a ``image_size`` window at the top-left corner, or at a random anchor with
+                    ``random_crop`` (two ``np.random.randint`` draws: row, then column, dataset.py:82-83);
+                    'resize' -- centre square crop, then bilinear resize to ``image_size`` (dataset.py:58-73).
+    ``image_count`` photos stored per sample, ``used_image_count`` photos wanted: the LAST
+                    ``min(image_count, used)`` stored ones are read (dataset.py:136-138), gamma-decoded unless
+                    ``is_linear``; missing ones are rendered later on the GPU (``complete_inputs``).
+    ``mix_materials`` only for ``image_count == 0`` (dataset.py:29-32): a partner sample is picked with python's
+                    ``random.randrange`` and a blend weight with ``torch`` U(0.1, 0.9) (dataset.py:52-56, :144) --
+                    same generators, same order -- and returned as ``svbrdf_other`` / ``mix_alpha``; the blend
+                    itself runs on the GPU for the whole batch (``apply_mixing`` -> kernel K4).  Mixing commutes
+                    with cropping exactly; with 'resize' it is applied after the resize (the reference blends first).
+    ``no_svbrdf``   photos only: a flat dummy SVBRDF (normals (0,0,1), everything else 0), dataset.py:116-124.
+
+    Returns {'inputs': [n,3,S,S], 'svbrdf': [12,S,S]} (+ 'svbrdf_other', 'mix_alpha' when mixing)."""
+
+    def __init__(self, directory, image_size=256, image_count=10, used_image_count=1, is_linear=False, scale_mode="crop",
+                 random_crop=False, mix_materials=False, no_svbrdf=False):
         self.paths = sorted(os.path.join(directory, f) for f in os.listdir(directory)
                             if os.path.isfile(os.path.join(directory, f)))
+        if scale_mode not in ("crop", "resize"):
+            raise ValueError("Unknown scale mode {}".format(scale_mode))
         self.image_size, self.image_count, self.used, self.is_linear = image_size, image_count, used_image_count, is_linear
+        self.scale_mode, self.random_crop, self.no_svbrdf = scale_mode, random_crop, no_svbrdf
+        self.mix_materials = mix_materials
+        if self.mix_materials and self.image_count > 0:
+            self.mix_materials = False
+            print("Warning: Material mixing is only supported for datasets without input images.")
 
     def __len__(self):
         return len(self.paths)
 
-    def __getitem__(self, idx):
-        photos, svbrdf = read_tiled_png(self.paths[idx], self.image_count)
+    def read_sample(self, path):
+        """-> (the last min(image_count, used) stored photos as stored, svbrdf [12,H,W]); dataset.py:105-140"""
+        if self.no_svbrdf:
+            from PIL import Image
+            img = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 255.0
+            parts = torch.stack(torch.from_numpy(img).permute(2, 0, 1).chunk(self.image_count, dim=-1), dim=0)
+            h, w = parts.shape[-2:]
+            normals = torch.cat((torch.zeros(2, h, w), torch.ones(1, h, w)), dim=0)
+            svbrdf = torch.cat((normals, torch.zeros(9, h, w)), dim=0)
+            photos = parts
+        else:
+            photos, svbrdf = read_tiled_png(path, self.image_count)
         keep = min(self.image_count, self.used)
-        photos = photos[self.image_count - keep:]                                     # the last ones, dataset.py:137
+        return photos[self.image_count - keep:self.image_count], svbrdf
+
+    def _scale(self, photos, svbrdfs):
+        """the reference's crop / resize of the photos and of every SVBRDF in `svbrdfs` with ONE anchor"""
+        height, width = svbrdfs[0].shape[-2:]
         S = self.image_size
-        photos, svbrdf = photos[..., :S, :S], svbrdf[..., :S, :S]                      # scale_mode 'crop', anchor 0
+        if self.scale_mode == "resize":
+            landscape = width > height
+            anchor = (0, (width - height) // 2) if landscape else ((height - width) // 2, 0)
+            size = height if landscape else width
+            photos = _crop_square(photos, anchor, size)
+            svbrdfs = [_crop_square(m, anchor, size) for m in svbrdfs]
+            interp = torch.nn.functional.interpolate
+            if photos.shape[0] > 0:
+                photos = interp(photos, size=(S, S), mode="bilinear")
+            else:
+                photos = photos.new_zeros((0, 3, S, S))
+            svbrdfs = [interp(m.unsqueeze(0), size=(S, S), mode="bilinear").squeeze(0) for m in svbrdfs]
+        else:
+            anchor = (0, 0)
+            if self.random_crop:
+                anchor = (np.random.randint(0, height - S + 1), np.random.randint(0, width - S + 1))
+            photos = _crop_square(photos, anchor, S)
+            svbrdfs = [_crop_square(m, anchor, S) for m in svbrdfs]
+        return photos, svbrdfs
+
+    def __getitem__(self, idx):
+        photos, svbrdf = self.read_sample(self.paths[idx])
+        maps, alpha = [svbrdf], None
+        if self.mix_materials:
+            import random
+            other = random.randrange(0, len(self))                                    # dataset.py:54
+            maps.append(self.read_sample(self.paths[other])[1])
+            alpha = synthesis.draw_mix_alpha()                                        # dataset.py:144
+        photos, maps = self._scale(photos, maps)
         if not self.is_linear:
             photos = utils.gamma_decode(photos)
-        return {"inputs": photos.contiguous(), "svbrdf": svbrdf.contiguous()}
+        item = {"inputs": photos.contiguous(), "svbrdf": maps[0].contiguous()}
+        if self.mix_materials:
+            item["svbrdf_other"], item["mix_alpha"] = maps[1].contiguous(), alpha
+        return item
+
+
+def apply_mixing(batch_svbrdf, batch):
+    """device side of the material-mixing augmentation: [B,12,H,W] maps + the collated batch of a mixing dataset
+    ('svbrdf_other' [B,12,H,W], 'mix_alpha' [B,1]) -> mixed maps (kernel K4).  A batch without those keys passes."""
+    if "svbrdf_other" not in batch:
+        return batch_svbrdf
+    other = batch["svbrdf_other"].to(batch_svbrdf.device, non_blocking=True)
+    return synthesis.mix_materials(batch_svbrdf, other, batch["mix_alpha"].reshape(-1))
 
 
 class SyntheticSvbrdfDataset(torch.utils.data.Dataset):

@@ -13,7 +13,8 @@ generator on N photos, max-pools feature maps and tracks over the photos and ref
 return the 9 encoded channels for ``losses.FusedHeadLoss`` (the decode then runs in the kernel).
 
 The convolutions stay on stock PyTorch-ROCm (MIOpen/hipBLASLt) by design (north star).  State-dict
-keys differ from the reference's; checkpoints are not interchangeable.
+keys differ from the reference's; ``convert_reference_state_dict`` / ``convert_to_reference_state_dict`` translate
+a ``checkpoint.tar``'s ``model_state_dict`` (persistence.py:52-69) in either direction.
 """
 import math
 
@@ -242,4 +243,44 @@ def convert_reference_state_dict(ref_state):
             out["pool_inject.%s" % m.group(1)] = value
             continue
         raise KeyError("unexpected key in reference state dict: %s" % key)
+    return out
+
+
+def convert_to_reference_state_dict(state):
+    """inverse of ``convert_reference_state_dict``: a state dict of the classes above -> the reference's key names
+    (so that a model trained here loads into the reference's SingleViewModel / MultiViewModel)."""
+    import re
+    out = {}
+    for key, value in state.items():
+        m = re.match(r"generator\.enc\.(\d)\.(.*)", key)
+        if m:
+            rest = m.group(2).replace("inject.", "merge.fully_connected.")
+            out["generator.enc%d.conv.%s" % (int(m.group(1)) + 1, rest)] = value
+            continue
+        m = re.match(r"generator\.dec\.(\d)\.(.*)", key)
+        if m:
+            rest = m.group(2).replace("inject.", "merge.fully_connected.")
+            out["generator.dec%d.deconv.%s" % (8 - int(m.group(1)), rest)] = value
+            continue
+        m = re.match(r"generator\.track_enc\.(\d)\.fc\.(.*)", key)
+        if m:
+            out["generator.gte%d.fully_connected.%s" % (int(m.group(1)) + 1, m.group(2))] = value
+            continue
+        m = re.match(r"generator\.track_dec\.(\d)\.fc\.(.*)", key)
+        if m:
+            out["generator.gtd%d.fully_connected.%s" % (8 - int(m.group(1)), m.group(2))] = value
+            continue
+        m = re.match(r"tracks\.(\d)\.fc\.(.*)", key)
+        if m:
+            out["gt%d.fully_connected.%s" % (int(m.group(1)) + 1, m.group(2))] = value
+            continue
+        m = re.match(r"convs\.(\d)\.(.*)", key)
+        if m:
+            out["conv%d.conv.%s" % (int(m.group(1)) + 1, m.group(2).replace("inject.", "merge.fully_connected."))] = value
+            continue
+        m = re.match(r"pool_inject\.(.*)", key)
+        if m:
+            out["merge.fully_connected.%s" % m.group(1)] = value
+            continue
+        raise KeyError("unexpected key: %s" % key)
     return out

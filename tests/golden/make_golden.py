@@ -329,6 +329,161 @@ def g11_head_loss():
     save("g11_head_loss.npz", enc9=enc, target=tgt, rng_seed=np.int64(17), **out)
 
 
+
+def _write_png(path, rows_hw3_uint8):
+    from PIL import Image
+    Image.fromarray(rows_hw3_uint8, mode="RGB").save(path)
+
+
+def g12_dataset_reader():
+    """row f4: the reference's SvbrdfDataset.read_sample / __getitem__ (dataset.py:44-140: chunk on width, normals
+    *2-1, the LAST n photos, scale modes 'crop' (anchor 0 or random) and 'resize' (centre crop + bilinear), gamma
+    decode) and mix (dataset.py:142-160), run on small tiled PNGs that are committed next to the outputs.
+      g12_tiled_synthetic.png   3 photos + 4 maps, tiles 56 wide x 40 high (landscape), random 8-bit content
+      g12_tiled_toy_crop.png    the top-left 64x64 of each of the 14 tiles of the reference's bundled toy sample
+                                data/train/10_1_parquet_floor_0.png (10 photos + 4 maps): real material statistics
+      g12_maps_only_{0,1}.png   4 map tiles of 32x32 (input_image_count = 0: the material-mixing configuration)"""
+    import random
+    import shutil
+    import tempfile
+    from PIL import Image
+    import dataset as ref_dataset
+
+    rng = np.random.RandomState(1234)
+    syn = rng.randint(0, 256, size=(40, 56 * 7, 3)).astype(np.uint8)
+    _write_png(os.path.join(HERE, "g12_tiled_synthetic.png"), syn)
+    toy = np.asarray(Image.open(os.path.join(REF, "data", "train", "10_1_parquet_floor_0.png")).convert("RGB"))
+    tw = toy.shape[1] // 14
+    crop = np.concatenate([toy[:64, k * tw:k * tw + 64] for k in range(14)], axis=1)
+    _write_png(os.path.join(HERE, "g12_tiled_toy_crop.png"), np.ascontiguousarray(crop))
+    for k in range(2):
+        m = rng.randint(0, 256, size=(32, 32 * 4, 3)).astype(np.uint8)
+        m[:, :32, 2] = np.maximum(m[:, :32, 2], 160)          # normals: mostly upward z ...
+        m[:4, :32, 2] = 128                                   # ... with a band at z ~ 0.004 (< the 0.01 floor of mix)
+        m[:, 64:96, 1] = m[:, 64:96, 0]
+        m[:, 64:96, 2] = m[:, 64:96, 0]                       # grey roughness, as the data stores it
+        _write_png(os.path.join(HERE, "g12_maps_only_%d.png" % k), m)
+
+    arrays = {}
+
+    def dataset_for(png, **kw):
+        d = tempfile.mkdtemp()
+        shutil.copy(os.path.join(HERE, png), d)
+        return ref_dataset.SvbrdfDataset(data_directory=d, use_augmentation=False, **kw), d
+
+    for tag, png, n in (("syn", "g12_tiled_synthetic.png", 3), ("toy", "g12_tiled_toy_crop.png", 10)):
+        size = 32
+        ds, d = dataset_for(png, image_size=size, scale_mode="crop", input_image_count=n, used_input_image_count=2)
+        photos, svbrdf = ds.read_sample(ds.file_paths[0])
+        arrays[tag + "__read_photos"] = photos.numpy()
+        arrays[tag + "__read_svbrdf"] = svbrdf.numpy()
+        item = ds[0]
+        arrays[tag + "__crop0_inputs"], arrays[tag + "__crop0_svbrdf"] = item["inputs"].numpy(), item["svbrdf"].numpy()
+        ds.random_crop = True
+        np.random.seed(5)
+        item = ds[0]
+        arrays[tag + "__randcrop_inputs"], arrays[tag + "__randcrop_svbrdf"] = item["inputs"].numpy(), item["svbrdf"].numpy()
+        arrays[tag + "__randcrop_np_seed"] = np.int64(5)
+        ds.random_crop = False
+        ds.is_linear = True
+        arrays[tag + "__crop0_linear_inputs"] = ds[0]["inputs"].numpy()
+        ds.is_linear = False
+        ds.scale_mode, ds.image_size = "resize", 24
+        item = ds[0]
+        arrays[tag + "__resize_inputs"], arrays[tag + "__resize_svbrdf"] = item["inputs"].numpy(), item["svbrdf"].numpy()
+        ds.used_input_image_count = 1
+        ds.scale_mode, ds.image_size = "crop", size
+        arrays[tag + "__crop0_used1_inputs"] = ds[0]["inputs"].numpy()
+        shutil.rmtree(d)
+
+    # mix (dataset.py:142-160): explicit alpha, and alpha drawn from the torch generator
+    fs = types.SimpleNamespace()
+    a = synth.make_maps(701, 1, 32)[0]
+    b = synth.make_maps(702, 1, 32, tilt=0.6)[0]
+    a[2, :3, :] = np.float32(0.004)                           # below the 0.01 floor of the projection
+    b[2, 5, :] = np.float32(-0.2)
+    arrays["mix__a"], arrays["mix__b"] = a, b
+    arrays["mix__alpha03"] = ref_dataset.SvbrdfDataset.mix(fs, torch.from_numpy(a), torch.from_numpy(b),
+                                                           alpha=torch.tensor([0.3])).numpy()
+    torch.manual_seed(9)
+    arrays["mix__drawn"] = ref_dataset.SvbrdfDataset.mix(fs, torch.from_numpy(a), torch.from_numpy(b)).numpy()
+    torch.manual_seed(9)
+    arrays["mix__drawn_alpha"] = torch.Tensor(1).uniform_(0.1, 0.9).numpy()
+    arrays["mix__seed"] = np.int64(9)
+
+    # __getitem__ with material mixing (input_image_count = 0; no photos requested, so nothing is rendered):
+    # python's random picks the partner, torch's generator the blend weight
+    d = tempfile.mkdtemp()
+    for k in range(2):
+        shutil.copy(os.path.join(HERE, "g12_maps_only_%d.png" % k), d)
+    ds = ref_dataset.SvbrdfDataset(data_directory=d, image_size=24, scale_mode="crop", input_image_count=0,
+                                   used_input_image_count=0, use_augmentation=False, mix_materials=True)
+    ds.file_paths = sorted(ds.file_paths)                     # os.listdir order is arbitrary: pin it
+    picked = []
+    orig = random.randrange
+
+    def spy(lo, hi):
+        v = orig(lo, hi)
+        picked.append(v)
+        return v
+    random.randrange = spy
+    try:
+        for idx in (0, 1):
+            random.seed(3 + idx)
+            torch.manual_seed(21 + idx)
+            item = ds[idx]
+            arrays["mixitem%d__svbrdf" % idx] = item["svbrdf"].numpy()
+            arrays["mixitem%d__inputs_shape" % idx] = np.array(item["inputs"].shape, np.int64)
+            arrays["mixitem%d__partner" % idx] = np.int64(picked[-1])
+            arrays["mixitem%d__rng_after" % idx] = torch.get_rng_state().numpy()[:64].copy()
+    finally:
+        random.randrange = orig
+        shutil.rmtree(d)
+    save("g12_dataset_reader.npz", **arrays)
+
+
+def _deterministic_state(ref_model, seed0):
+    """state dict with the reference's keys/shapes, values from tests/synth.py (platform-independent): each tensor
+    uniform with the mean and standard deviation the reference's own initialisation gave it"""
+    state, stats = {}, []
+    for i, (k, v) in enumerate(ref_model.state_dict().items()):
+        mean = np.float32(v.float().mean().item())
+        std = np.float32(v.float().std().item()) if v.numel() > 1 else np.float32(0.0)
+        u = synth.uniform01(seed0 + i, tuple(v.shape)) - np.float32(0.5)
+        w = (u * (np.float32(3.4641016) * std) + mean).astype(np.float32)
+        state[k] = torch.from_numpy(w.reshape(tuple(v.shape)))
+        stats.append((k, tuple(v.shape), float(mean), float(std)))
+    return state, stats
+
+
+def g13_unet_forward():
+    """row f4: forward pass of the reference's SingleViewModel / MultiViewModel (models.py:322-411) with a state dict
+    the test can regenerate bit for bit (tests/synth.py values, keyed by the reference's parameter names), outputs
+    on a stride-8 lattice.  Lets the GPU box check the MIOpen forward of the re-stated network."""
+    import models as ref_models
+    arrays = {}
+    for tag, cls, shape, seed0 in (("single", ref_models.SingleViewModel, (1, 3, 256, 256), 9000),
+                                   ("multi", ref_models.MultiViewModel, (1, 2, 3, 256, 256), 9500)):
+        torch.manual_seed(0)
+        model = cls(use_coords=True).eval()
+        state, stats = _deterministic_state(model, seed0)
+        model.load_state_dict(state)
+        x = synth.uniform01(seed0 + 400, shape)
+        with torch.no_grad():
+            y = model(torch.from_numpy(x)).numpy()
+        arrays[tag + "__keys"] = np.array([k for k, _, _, _ in stats])
+        arrays[tag + "__shapes"] = np.array([",".join(map(str, sh)) for _, sh, _, _ in stats])
+        arrays[tag + "__mean"] = np.array([m for _, _, m, _ in stats], np.float32)
+        arrays[tag + "__std"] = np.array([sd for _, _, _, sd in stats], np.float32)
+        arrays[tag + "__seed0"] = np.int64(seed0)
+        arrays[tag + "__input_seed"] = np.int64(seed0 + 400)
+        arrays[tag + "__input_shape"] = np.array(shape, np.int64)
+        arrays[tag + "__out_lattice"] = y[:, :, ::8, ::8].copy()
+        arrays[tag + "__out_plane_sums"] = y.astype(np.float64).sum(axis=(2, 3))
+        arrays[tag + "__out_absmax"] = np.float32(np.abs(y).max())
+    save("g13_unet_forward.npz", **arrays)
+
+
 def g9_kat():
     R = ref_renderers.LocalRenderer()
     out = {}
@@ -366,6 +521,12 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--only-head-loss":      # row f1, added later
         g11_head_loss()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-dataset":        # row f4 reader + mix, added in round 2
+        g12_dataset_reader()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-unet":           # row f4 network forward, added in round 2
+        g13_unet_forward()
+        return
     g1_render_64()
     g2_lattice(256, 8, 111)
     g2_lattice(512, 16, 112)
@@ -379,6 +540,8 @@ def main():
     g9_kat()
     g10_render_inputs()
     g11_head_loss()
+    g12_dataset_reader()
+    g13_unet_forward()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "mworchel/svbrdf-estimation @ /root/reference (development/multiImage_pytorch)",

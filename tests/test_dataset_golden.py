@@ -1,0 +1,126 @@
+"""CPU: rows f3/f4 pinned against the reference -- the tiled-PNG reader, its scale modes and the material-mixing
+sequence against outputs of the reference's SvbrdfDataset (dataset.py:44-160) on the committed sample PNGs, and the
+re-stated network against a forward pass of the reference's models with a regenerable state dict
+(tests/golden/make_golden.py g12 / g13).  The K4 mix kernel itself is checked on the GPU (test_gpu_parity.py)."""
+import os
+import random
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _dataset(tmp_path, pngs, **kw):
+    from svbrdf_estimation_amd.training import data
+    d = tmp_path / "ds"
+    d.mkdir()
+    for p in pngs:
+        shutil.copy(os.path.join(GOLD, p), str(d))
+    return data.TiledPngDataset(str(d), **kw)
+
+
+@pytest.mark.parametrize("tag,png,n", [("syn", "g12_tiled_synthetic.png", 3), ("toy", "g12_tiled_toy_crop.png", 10)])
+def test_reader_equals_reference_read_sample_and_getitem(tmp_path, golden, tag, png, n):
+    """bit for bit: chunking, normals *2-1, the LAST photos, crop at 0 / random anchor (same numpy draws),
+    centre-crop + bilinear resize (landscape tiles in the synthetic sample), gamma decode, linear input"""
+    g = golden("g12_dataset_reader.npz")
+    ds = _dataset(tmp_path, [png], image_size=32, scale_mode="crop", image_count=n, used_image_count=2)
+    photos, svbrdf = ds.read_sample(ds.paths[0])
+    assert np.array_equal(photos.numpy(), g[tag + "__read_photos"])
+    assert np.array_equal(svbrdf.numpy(), g[tag + "__read_svbrdf"])
+    item = ds[0]
+    assert np.array_equal(item["inputs"].numpy(), g[tag + "__crop0_inputs"])
+    assert np.array_equal(item["svbrdf"].numpy(), g[tag + "__crop0_svbrdf"])
+    ds.random_crop = True
+    np.random.seed(int(g[tag + "__randcrop_np_seed"]))
+    item = ds[0]
+    assert np.array_equal(item["inputs"].numpy(), g[tag + "__randcrop_inputs"])
+    assert np.array_equal(item["svbrdf"].numpy(), g[tag + "__randcrop_svbrdf"])
+    assert not np.array_equal(g[tag + "__randcrop_svbrdf"], g[tag + "__crop0_svbrdf"])     # the anchor did move
+    ds.random_crop, ds.is_linear = False, True
+    assert np.array_equal(ds[0]["inputs"].numpy(), g[tag + "__crop0_linear_inputs"])
+    ds.is_linear, ds.scale_mode, ds.image_size = False, "resize", 24
+    item = ds[0]
+    assert np.array_equal(item["inputs"].numpy(), g[tag + "__resize_inputs"])
+    assert np.array_equal(item["svbrdf"].numpy(), g[tag + "__resize_svbrdf"])
+    ds.used, ds.scale_mode, ds.image_size = 1, "crop", 32
+    assert np.array_equal(ds[0]["inputs"].numpy(), g[tag + "__crop0_used1_inputs"])
+
+
+def test_reader_rejects_unknown_scale_mode_and_mixing_with_stored_photos(tmp_path, capsys):
+    with pytest.raises(ValueError):
+        _dataset(tmp_path, ["g12_tiled_synthetic.png"], scale_mode="stretch", image_count=3)
+    shutil.rmtree(str(tmp_path / "ds"))
+    ds = _dataset(tmp_path, ["g12_tiled_synthetic.png"], image_count=3, mix_materials=True)
+    assert ds.mix_materials is False and "only supported" in capsys.readouterr().out      # dataset.py:29-32
+
+
+def test_mixing_dataset_draws_partner_and_weight_like_the_reference(tmp_path, golden):
+    """python's `random` picks the partner sample, torch's generator the blend weight, in that order
+    (dataset.py:52-56, :144); the two SVBRDFs and the weight are what the GPU mix then consumes"""
+    g = golden("g12_dataset_reader.npz")
+    ds = _dataset(tmp_path, ["g12_maps_only_0.png", "g12_maps_only_1.png"], image_size=24, scale_mode="crop",
+                  image_count=0, used_image_count=0, mix_materials=True)
+    for idx in (0, 1):
+        random.seed(3 + idx)
+        torch.manual_seed(21 + idx)
+        item = ds[idx]
+        assert np.array_equal(torch.get_rng_state().numpy()[:64], g["mixitem%d__rng_after" % idx])
+        partner = int(g["mixitem%d__partner" % idx])
+        other = ds.read_sample(ds.paths[partner])[1][:, :24, :24]
+        assert torch.equal(item["svbrdf_other"], other)
+        assert tuple(item["inputs"].shape) == tuple(g["mixitem%d__inputs_shape" % idx])
+        # the literal formula on the host (test-side restatement of dataset.py:142-160) reproduces the reference's item
+        mixed = _mix_restated(item["svbrdf"], item["svbrdf_other"], item["mix_alpha"])
+        assert np.allclose(mixed.numpy(), g["mixitem%d__svbrdf" % idx], rtol=0, atol=2e-7)
+
+
+def _mix_restated(a, b, alpha):
+    n0, n1 = a[0:3] / torch.max(torch.tensor([0.01]), a[2:3]), b[0:3] / torch.max(torch.tensor([0.01]), b[2:3])
+    n = alpha * n0 + (1.0 - alpha) * n1
+    n = n / torch.sqrt(torch.sum(n ** 2, dim=0, keepdim=True))
+    return torch.cat((n, alpha * a[3:] + (1.0 - alpha) * b[3:]), dim=0)
+
+
+def _regenerated_state(g, tag):
+    state = {}
+    for i, (key, shape) in enumerate(zip(g[tag + "__keys"], g[tag + "__shapes"])):
+        shp = tuple(int(v) for v in str(shape).split(",")) if str(shape) else ()
+        u = synth.uniform01(int(g[tag + "__seed0"]) + i, shp) - np.float32(0.5)
+        w = (u * (np.float32(3.4641016) * g[tag + "__std"][i]) + g[tag + "__mean"][i]).astype(np.float32)
+        state[str(key)] = torch.from_numpy(w.reshape(shp))
+    return state
+
+
+def unet_against_fixture(golden, tag, device, rtol, atol):
+    from svbrdf_estimation_amd.training import models
+    g = golden("g13_unet_forward.npz")
+    ref_state = _regenerated_state(g, tag)
+    cls = models.SingleViewModel if tag == "single" else models.MultiViewModel
+    net = cls(use_coords=True).eval()
+    net.load_state_dict(models.convert_reference_state_dict(ref_state))
+    back = models.convert_to_reference_state_dict(net.state_dict())
+    assert set(back) == set(ref_state) and all(torch.equal(back[k], ref_state[k]) for k in ref_state)
+    x = torch.from_numpy(synth.uniform01(int(g[tag + "__input_seed"]), tuple(int(v) for v in g[tag + "__input_shape"])))
+    net = net.to(device)
+    with torch.no_grad():
+        y = net(x.to(device)).float().cpu().numpy()
+    lat = y[:, :, ::8, ::8]
+    err = np.abs(lat - g[tag + "__out_lattice"])
+    assert (err <= atol + rtol * np.abs(g[tag + "__out_lattice"])).all(), "max abs err %.3e" % err.max()
+    sums = y.astype(np.float64).sum(axis=(2, 3))
+    assert np.allclose(sums, g[tag + "__out_plane_sums"], rtol=0, atol=256 * 256 * atol)
+    return float(err.max())
+
+
+@pytest.mark.parametrize("tag", ["single", "multi"])
+def test_unet_forward_equals_reference_fixture_cpu(golden, tag):
+    """the re-stated network (stock torch.nn on the CPU backend here) against the reference's forward pass with the
+    same regenerated weights; the GPU suite repeats this on the MIOpen path"""
+    torch.set_num_threads(8)
+    unet_against_fixture(golden, tag, torch.device("cpu"), rtol=1e-4, atol=3e-5)

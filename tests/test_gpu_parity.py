@@ -720,6 +720,137 @@ def test_training_harness_single_gpu_loss_decreases(dev, tmp_path):
     assert np.isfinite(train.run(args)["loss_last_quarter"])
 
 
+# ---------------------------------------------------------------- BASELINE configs[3] at its size
+
+def test_config4_batch16_mixed_loss_module_path(dev, native, oracle):
+    """configs[3]: batch 16, 256x256, 9 scenes, MixedLoss -- the loss shapes of the multi-view network's output.
+    B*S = 144 scene rows exceed the kernel-argument route (96), so the module path uploads the table (pinned ring)
+    and runs the device-table kernel.  Checked at EVERY pixel of all 16 items against the C oracle, plus the
+    size-independent properties (halves average to the whole, determinism, both host paths bitwise equal)."""
+    from svbrdf_estimation_amd import _hostext, losses, renderers
+    B, H, S = 16, 256, 9
+    assert B * S > native.host_scenes_max_rows()
+    inp, tgt = synth.make_maps(1601, B, H), synth.make_maps(1602, B, H)
+    d_in, d_tg = _t(inp, dev), _t(tgt, dev)
+    loss_fn = losses.MixedLoss(renderers.LocalRenderer())
+    torch.manual_seed(77)
+    table = loss_fn.rendering_loss.sample_scene_table(B)
+    res = []
+    try:
+        for enabled in (True, False):                  # native host extension, then python + ctypes
+            _hostext.set_enabled(enabled)
+            x = d_in.clone().requires_grad_(True)
+            torch.manual_seed(77)
+            loss = loss_fn(x, d_tg)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((loss.item(), x.grad.clone()))
+    finally:
+        _hostext.set_enabled(True)
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    oracle.set_threads(min(32, oracle.max_threads()))
+    ref_l, ref_g = oracle.mixed_loss(inp, tgt, table.numpy(), 0.1)
+    assert_loss_close(res[0][0], ref_l, "config 4 mixed loss")
+    _, g64 = oracle.mixed_loss(inp, tgt, table.numpy(), 0.1, f64=True)
+    ties = oracle.loss_tie_map(inp, tgt, table.numpy())
+    assert_grad_close(_np(res[0][1]), ref_g, "config 4 mixed-loss gradient", f64=g64, tie_map=ties)
+    # halves: the batch loss is the mean of the two half-batch losses, the gradient of an item is 1/2 of its gradient
+    # in a half-batch call (the mean's denominator)
+    lo = native.rendering_loss(d_in[:8].contiguous(), d_tg[:8].contiguous(), table[:8].contiguous(), l1_weight=0.1)
+    hi = native.rendering_loss(d_in[8:].contiguous(), d_tg[8:].contiguous(), table[8:].contiguous(), l1_weight=0.1)
+    assert abs(0.5 * (lo[0].item() + hi[0].item()) - res[0][0]) <= 2e-7 * abs(res[0][0])
+    halves = torch.cat((lo[1], hi[1]), dim=0) * 0.5
+    assert_grad_close(_np(res[0][1]), _np(halves), "config 4 halves", rtol=2e-6, afrac=1e-7)
+    # determinism of the device-table route (fixed-point loss reduction)
+    again = native.rendering_loss(d_in, d_tg, native.upload_scene_table(table, dev), l1_weight=0.1)
+    assert again[0].item() == res[0][0] and torch.equal(again[1], res[0][1])
+
+
+@pytest.mark.timeout(900)
+def test_config4_training_harness_multi_view_5_batch_16(dev):
+    """configs[3] through train.py: multi-view network (N = 5 photos, pooled encoder, models.py:348-411), batch 16,
+    mixed loss, photos synthesised on the GPU -- a few steps at size"""
+    import train
+    args = train.parse_args(["--model", "multi", "--views", "5", "--batch", "16", "--steps", "1", "--warmup", "1",
+                             "--workers", "0", "--samples", "16"])
+    res = train.run(args)
+    assert res["config"]["views"] == 5 and res["config"]["per_gpu_batch"] == 16
+    assert np.isfinite(res["loss_first_quarter"]) and np.isfinite(res["loss_last_quarter"])
+    print("config 4 end to end: %.1f patches/s (%.0f ms per step)" % (res["value"], res["ms_per_step"]))
+
+
+# ---------------------------------------------------------------- rows f3 / f4 pinned against the reference
+
+def _mix_restated_cpu(a, b, alpha):
+    """test-side restatement of dataset.py:142-160 on the host, for shapes the fixture does not hold"""
+    a, b, alpha = torch.as_tensor(a), torch.as_tensor(b), torch.as_tensor(alpha, dtype=torch.float32).view(-1, 1, 1, 1)
+    n0, n1 = a[:, 0:3] / torch.clamp(a[:, 2:3], min=0.01), b[:, 0:3] / torch.clamp(b[:, 2:3], min=0.01)
+    n = alpha * n0 + (1.0 - alpha) * n1
+    n = n / torch.sqrt((n[:, 0:1] ** 2 + n[:, 1:2] ** 2) + n[:, 2:3] ** 2)
+    return torch.cat((n, alpha * a[:, 3:] + (1.0 - alpha) * b[:, 3:]), dim=1).numpy()
+
+
+def test_mix_materials_kernel_equals_reference_mix(dev, native, golden):
+    """K4 against the reference's SvbrdfDataset.mix (dataset.py:142-160): explicit weight, weight drawn from the
+    torch generator (same draw), the z < 0.01 projection floor, negative z; blended diffuse/roughness/specular bit
+    for bit, normals within 2 ULP (torch's CPU sqrt is not correctly rounded)"""
+    from svbrdf_estimation_amd import synthesis
+    g = golden("g12_dataset_reader.npz")
+    a, b = _t(g["mix__a"], dev), _t(g["mix__b"], dev)
+    out = _np(synthesis.mix_materials(a, b, 0.3))
+    assert np.array_equal(out[3:], g["mix__alpha03"][3:])
+    assert np.abs(out[:3] - g["mix__alpha03"][:3]).max() <= 2.4e-7
+    torch.manual_seed(int(g["mix__seed"]))
+    out = _np(synthesis.mix_materials(a, b))
+    assert np.array_equal(out[3:], g["mix__drawn"][3:]) and np.abs(out[:3] - g["mix__drawn"][:3]).max() <= 2.4e-7
+    # batch with one weight per item, ragged sizes (every vector width), H != W
+    for (B, H, W) in ((3, 7, 9), (2, 6, 10), (2, 16, 24), (1, 5, 5)):
+        m0, m1 = synth.make_maps(710 + H, B, H, W, unit_normals=False), synth.make_maps(720 + W, B, H, W, tilt=0.8)
+        m0[:, 2, 0, :] = np.float32(0.003)
+        alpha = np.linspace(0.1, 0.9, B).astype(np.float32)
+        got = _np(native.mix_materials(_t(m0, dev), _t(m1, dev), _t(alpha, dev)))
+        ref = _mix_restated_cpu(m0, m1, alpha)
+        assert np.array_equal(got[:, 3:], ref[:, 3:]), (B, H, W)
+        assert np.abs(got[:, :3] - ref[:, :3]).max() <= 2.4e-7, (B, H, W)
+    lib = native._load()
+    p = a.data_ptr()
+    assert lib.svbrdf_mix_materials(None, p, p, p, 1, 4, 4, None) == -1
+    assert lib.svbrdf_mix_materials(p, p, p, p, 0, 4, 4, None) == -2
+
+
+def test_mixing_dataset_item_through_the_gpu_mix(dev, golden, tmp_path):
+    """SvbrdfDataset.__getitem__ with material mixing (dataset.py:52-56): dataset (host: partner + weight draws)
+    -> collate -> apply_mixing (K4) reproduces the reference's mixed SVBRDF"""
+    import random
+    import shutil
+    from svbrdf_estimation_amd.training import data
+    g = golden("g12_dataset_reader.npz")
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for k in range(2):
+        shutil.copy(os.path.join(gdir, "g12_maps_only_%d.png" % k), str(tmp_path))
+    ds = data.TiledPngDataset(str(tmp_path), image_size=24, scale_mode="crop", image_count=0, used_image_count=0,
+                              mix_materials=True)
+    items = []
+    for idx in (0, 1):
+        random.seed(3 + idx)
+        torch.manual_seed(21 + idx)
+        items.append(ds[idx])
+    batch = torch.utils.data.default_collate(items)
+    mixed = _np(data.apply_mixing(batch["svbrdf"].to(dev), batch))
+    for idx in (0, 1):
+        ref = g["mixitem%d__svbrdf" % idx]
+        assert np.array_equal(mixed[idx, 3:], ref[3:]) and np.abs(mixed[idx, :3] - ref[:3]).max() <= 2.4e-7
+
+
+@pytest.mark.parametrize("tag", ["single", "multi"])
+def test_unet_forward_equals_reference_fixture_on_the_gpu(dev, golden, tag):
+    """the re-stated network on the MIOpen path against the reference's forward pass (regenerated weights, fixture
+    g13): what test_training_models.py can only check where the reference is mounted"""
+    from test_dataset_golden import unet_against_fixture
+    err = unet_against_fixture(golden, tag, dev, rtol=1e-3, atol=3e-4)
+    print("U-Net %s on the GPU vs reference fixture: max abs err %.2e" % (tag, err))
+
+
 # ---------------------------------------------------------------- streams
 
 def test_non_default_and_concurrent_streams(dev, native, golden):

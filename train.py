@@ -38,6 +38,12 @@ def parse_args(argv=None):
                     help="ranks (one per GPU).  0: whatever the launcher's WORLD_SIZE says (1 without a launcher)")
     ap.add_argument("--data", default="synthetic", help="'synthetic' or a directory of tiled PNG samples")
     ap.add_argument("--image-count", type=int, default=10, help="photos stored per tiled PNG")
+    ap.add_argument("--scale-mode", choices=("crop", "resize"), default="crop")      # cli.py scale mode, dataset.py:58-89
+    ap.add_argument("--random-crop", action="store_true")
+    ap.add_argument("--mix-materials", action="store_true",
+                    help="material-mixing augmentation (dataset.py:52-56, 142-160; main.py:49 enables it for training): "
+                         "partner and weight drawn in the dataloader, blend on the GPU (kernel K4); needs --image-count 0")
+    ap.add_argument("--linear-input", action="store_true")
     ap.add_argument("--model", choices=("single", "multi"), default="single")
     ap.add_argument("--views", type=int, default=1, help="input photos per sample (multi-view: N)")
     ap.add_argument("--size", type=int, default=256)
@@ -122,7 +128,9 @@ def run(args):
         dataset = data.SyntheticSvbrdfDataset(n, image_size=args.size, seed=args.seed)
     else:
         dataset = data.TiledPngDataset(args.data, image_size=args.size, image_count=args.image_count,
-                                       used_image_count=args.views)
+                                       used_image_count=args.views, is_linear=args.linear_input,
+                                       scale_mode=args.scale_mode, random_crop=args.random_crop,
+                                       mix_materials=args.mix_materials)
     sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True,
                                                               seed=args.seed, drop_last=True) if world > 1 else None
     loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch, sampler=sampler, shuffle=sampler is None,
@@ -150,6 +158,7 @@ def run(args):
         svbrdf = batch["svbrdf"].to(dev, non_blocking=True)
         stored = batch["inputs"].to(dev, non_blocking=True)
         if on_gpu:
+            svbrdf = data.apply_mixing(svbrdf, batch)                            # K4: material mixing, whole batch
             photos = data.complete_inputs(stored, svbrdf, args.views)           # K1: missing photos, whole batch
         else:                                                                    # CPU plumbing runs: constant photos
             photos = torch.cat((stored, svbrdf[:, None, 3:6].expand(-1, max(args.views - stored.shape[1], 0), -1, -1, -1)), 1)
