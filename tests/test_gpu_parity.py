@@ -399,7 +399,9 @@ def test_config5_size_512_32_scenes(dev, native, oracle):
     ref_l, ref_g = oracle.mixed_loss(inp, tgt, table, 0.1)
     _, g64 = oracle.mixed_loss(inp, tgt, table, 0.1, f64=True)
     assert_loss_close(loss.item(), ref_l, "config-5 mixed loss")
-    assert_grad_close(_np(x.grad), ref_g, "config-5 gradient", f64=g64, tie_map=oracle.loss_tie_map(inp, tgt, table))
+    # expected ties ~ 2e-6 per (pixel, scene, channel) term; measured 0.6e-6 (31 of 524288 pixels at 512x512, 32 scenes); the cap allows 2e-6
+    assert_grad_close(_np(x.grad), ref_g, "config-5 gradient", f64=g64, tie_map=oracle.loss_tie_map(inp, tgt, table),
+                      max_ties=max(8, int(2e-6 * inp.shape[0] * inp.shape[2] * inp.shape[3] * table.shape[1] * 3)))
 
 
 # ---------------------------------------------------------------- plugin interface (renderers.py:67)
@@ -421,7 +423,8 @@ def test_large_patch_1024(dev, native, oracle):
     ref_l, ref_g = oracle.rendering_loss(maps, tgt, table)
     _, g64 = oracle.rendering_loss(maps, tgt, table, f64=True)
     assert_loss_close(loss.item(), ref_l, "1024 loss")
-    assert_grad_close(_np(grad), ref_g, "1024 loss grad", f64=g64, tie_map=oracle.loss_tie_map(maps, tgt, table))
+    assert_grad_close(_np(grad), ref_g, "1024 loss grad", f64=g64, tie_map=oracle.loss_tie_map(maps, tgt, table),
+                      max_ties=max(8, int(2e-6 * maps.shape[0] * maps.shape[2] * maps.shape[3] * table.shape[1] * 3)))
 
 
 def test_local_renderer_interface(dev, oracle, golden):
@@ -753,7 +756,8 @@ def test_config4_batch16_mixed_loss_module_path(dev, native, oracle):
     assert_loss_close(res[0][0], ref_l, "config 4 mixed loss")
     _, g64 = oracle.mixed_loss(inp, tgt, table.numpy(), 0.1, f64=True)
     ties = oracle.loss_tie_map(inp, tgt, table.numpy())
-    assert_grad_close(_np(res[0][1]), ref_g, "config 4 mixed-loss gradient", f64=g64, tie_map=ties)
+    assert_grad_close(_np(res[0][1]), ref_g, "config 4 mixed-loss gradient", f64=g64, tie_map=ties,
+                      max_ties=max(8, int(2e-6 * B * H * H * S * 3)))
     # halves: the batch loss is the mean of the two half-batch losses, the gradient of an item is 1/2 of its gradient
     # in a half-batch call (the mean's denominator)
     lo = native.rendering_loss(d_in[:8].contiguous(), d_tg[:8].contiguous(), table[:8].contiguous(), l1_weight=0.1)

@@ -6,7 +6,7 @@ Renderings, fp32, identical inputs:
   coords -> NH path; they differ only by a few ULP in well-conditioned places).
 
   Against the REFERENCE's own outputs (golden fixtures) the same bound must hold for
-  >= 99.9 % of the pixels, and every pixel must satisfy
+  all but MAX_WIDENED_RENDER pixels (an absolute cap, counted and printed), and every pixel must satisfy
     |a-b| <= 1e-5*|b| + 1e-6*max|b| + 2*|b - f64|
   where f64 is the double-precision evaluation of the reference's formulas on the
   same fp32 inputs.  Reason (measured, tests/golden/make_golden.py header): torch's
@@ -50,10 +50,25 @@ def assert_render_strict(a, b, what="rendering", scale=None):
         what, bad, err.size, err.max() / max(scale, 1e-30))
 
 
-def assert_render_vs_reference(a, ref, f64, what="rendering", scale=None):
+# Hard caps on how many elements may use an allowance, so that a regression cannot hide inside one.  Every use is
+# printed (pytest -s / -rP) and recorded in ALLOWANCES_USED for the summary test.
+MAX_WIDENED_RENDER = 32      # pixels of a rendering fixture that need the "+ 2|ref - f64|" widening (measured: <= 9)
+MAX_WIDENED_GRAD = 64        # gradient elements that need it (measured: <= 21 on the fixtures, 0 on most)
+MAX_TIE_PIXELS = 8           # default cap on tie-excluded pixels; at-size tests pass their own (printed) cap
+TIE_SLACK = 0.5              # a tie pixel's gradient may differ by at most this fraction of max|gradient|
+ALLOWANCES_USED = []
+
+
+def _record(what, kind, count, total, cap):
+    ALLOWANCES_USED.append((what, kind, int(count), int(total), int(cap)))
+    print("[tolerance] %-44s %-22s %5d of %9d (cap %d)" % (what, kind, count, total, cap))
+
+
+def assert_render_vs_reference(a, ref, f64, what="rendering", scale=None, max_widened=MAX_WIDENED_RENDER):
     err, tol, scale = _viol(a, ref, RENDER_RTOL, RENDER_ATOL_FRAC, scale)
-    frac_ok = float((err <= tol).mean())
-    assert frac_ok >= 0.999, "%s: only %.4f%% of pixels within the strict bound" % (what, 100 * frac_ok)
+    widened = int((err > tol).sum())
+    _record(what, "widened by 2|ref-f64|", widened, err.size, max_widened)
+    assert widened <= max_widened, "%s: %d pixels outside the strict bound (cap %d)" % (what, widened, max_widened)
     own = 2.0 * np.abs(np.asarray(ref, np.float64) - np.asarray(f64, np.float64))
     bad = int((err > tol + own).sum())
     assert bad == 0, "%s: %d pixels differ by more than the reference's own rounding error" % (what, bad)
@@ -62,20 +77,28 @@ def assert_render_vs_reference(a, ref, f64, what="rendering", scale=None):
 TIE_LEVEL = 1e-6     # |log a - log b| below this: sign() in the L1 gradient is rounding noise
 
 
-def assert_grad_close(a, b, what="gradient", rtol=GRAD_RTOL, afrac=GRAD_ATOL_FRAC, f64=None, tie_map=None):
-    """tie_map [B,H,W] (oracle.loss_tie_map): pixels where some |log difference| < TIE_LEVEL are excluded --
-    there the sign of that term, hence the gradient, is undetermined in fp32 for the reference too (expected
-    fraction ~ 2e-6 per term and pixel: 6e-5 of the pixels at 32 scenes, measured 31 of 524288); they must stay
-    below 1e-3 of the pixels."""
+def assert_grad_close(a, b, what="gradient", rtol=GRAD_RTOL, afrac=GRAD_ATOL_FRAC, f64=None, tie_map=None,
+                      max_ties=MAX_TIE_PIXELS, max_widened=MAX_WIDENED_GRAD):
+    """tie_map [B,H,W] (oracle.loss_tie_map): pixels where some |log difference| < TIE_LEVEL are excluded from the
+    element-wise bound -- there the sign of that term, hence the gradient, is undetermined in fp32 for the reference
+    too (expected fraction ~ 2e-6 per term and pixel: 6e-5 of the pixels at 32 scenes, measured 31 of 524288).  They
+    are counted against `max_ties` and must still stay within TIE_SLACK * max|gradient| (one flipped term moves a
+    gradient by ~10 %; anything larger is a bug, not a tie)."""
     extra = None if f64 is None else 2.0 * np.abs(np.asarray(b, np.float64) - np.asarray(f64, np.float64))
     err, tol, scale = _viol(a, b, rtol, afrac, extra=extra)
     if tie_map is not None:
         ties = np.asarray(tie_map) < TIE_LEVEL
-        assert ties.mean() < 1e-3 or ties.sum() <= 2, "%s: %d tie pixels" % (what, int(ties.sum()))
+        n_ties = int(ties.sum())
+        _record(what, "tie pixels excluded", n_ties, ties.size, max_ties)
+        assert n_ties <= max_ties, "%s: %d tie pixels (cap %d)" % (what, n_ties, max_ties)
+        tie_err = np.where(ties[:, None, :, :], err, 0.0)
+        assert tie_err.max() <= TIE_SLACK * scale, "%s: a tie pixel is off by %.3e of max" % (what, tie_err.max() / scale)
         err = np.where(ties[:, None, :, :], 0.0, err)
     if f64 is not None:    # the widened bound may only be needed for a handful of elements
-        strict_ok = float((err <= rtol * np.abs(np.asarray(b, np.float64)) + afrac * scale).mean())
-        assert strict_ok >= 0.999, "%s: only %.4f%% of elements within the strict bound" % (what, 100 * strict_ok)
+        strict = rtol * np.abs(np.asarray(b, np.float64)) + afrac * scale
+        widened = int((err > strict).sum())
+        _record(what, "widened by 2|ref-f64|", widened, err.size, max_widened)
+        assert widened <= max_widened, "%s: %d elements outside the strict bound (cap %d)" % (what, widened, max_widened)
     bad = int((err > tol).sum())
     assert bad == 0, "%s: %d/%d outside %.0e rel + %.0e*max (max err/max %.3e)" % (
         what, bad, err.size, rtol, afrac, err.max() / max(scale, 1e-30))
