@@ -74,6 +74,19 @@ SVBRDF_API int svbrdf_render_bwd(const float *maps, const float *scenes, const f
                       const float *grad_out, float *grad_maps,
                       int B, int S, int H, int W, void *stream);
 
+/* Ragged forms of K1 / K2 (SURVEY section 8b "arbitrary (map, scene) pairs in one launch"): R renders in all, grouped
+ * by map -- the renders of map b are rows offsets[b] .. offsets[b+1]-1 of `scenes` [R,9] and of `out` / `grad_out`
+ * [R,3,H,W]; `offsets` is a DEVICE array of B+1 int32 with offsets[0] = 0 and offsets[B] = R (CSR row pointers; a map
+ * may have zero renders).  One launch, each map read once, no atomics: bitwise reproducible like the regular forms, of
+ * which these are the generalisation (offsets[b] = b*S).  The proposal's per-render `map_index` is this layout's
+ * inverse; grouping by map is what lets the backward accumulate in registers instead of with float atomics.
+ * svbrdf_render_bwd_ragged overwrites ALL of grad_maps (zeros for a map without renders). */
+SVBRDF_API int svbrdf_render_fwd_ragged(const float *maps, const float *scenes, const int *offsets, const float *xrow,
+                                        float *out, int B, int R, int H, int W, void *stream);
+SVBRDF_API int svbrdf_render_bwd_ragged(const float *maps, const float *scenes, const int *offsets, const float *xrow,
+                                        const float *grad_out, float *grad_maps, int B, int R, int H, int W,
+                                        void *stream);
+
 /* Bytes of device scratch svbrdf_rendering_loss_fwd_bwd needs for these dims (65 64-bit
  * words: sharded fixed-point loss accumulators with arrival counts, and a ticket).  The scratch must be
  * 8-byte aligned and ZERO-INITIALISED ONCE by the caller (hipMemset) before its first use;

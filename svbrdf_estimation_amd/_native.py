@@ -199,6 +199,61 @@ def render_bwd(maps, scenes, grad_out):
     return grad
 
 
+def _ragged_offsets(counts, B, R, device):
+    counts = [int(c) for c in counts]
+    if len(counts) != B or any(c < 0 for c in counts) or sum(counts) != R:
+        raise ValueError("counts must hold one non-negative render count per map and sum to the number of scenes")
+    off = [0]
+    for c in counts:
+        off.append(off[-1] + c)
+    return torch.tensor(off, dtype=torch.int32).to(device)
+
+
+def _ragged_binding():
+    lib = _load()
+    lib.svbrdf_render_fwd_ragged.argtypes = [_fp, _fp, _fp, _fp, _fp] + [ctypes.c_int] * 4 + [_fp]
+    lib.svbrdf_render_bwd_ragged.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp] + [ctypes.c_int] * 4 + [_fp]
+    lib.svbrdf_render_fwd_ragged.restype = lib.svbrdf_render_bwd_ragged.restype = ctypes.c_int
+    return lib
+
+
+def render_fwd_ragged(maps, scenes, counts):
+    """K1, ragged: maps [B,12,H,W], scenes [R,9] grouped by map, counts[b] renders for map b -> [R,3,H,W]."""
+    _require_device_f32(maps, "maps")
+    _require_device_f32(scenes, "scenes")
+    maps, scenes = maps.contiguous(), scenes.contiguous()
+    if maps.dim() != 4 or maps.shape[1] != 12 or maps.shape[2] != maps.shape[3] or scenes.dim() != 2 or scenes.shape[1] != 9:
+        raise ValueError("maps must be [B,12,H,H] and scenes [R,9]")
+    B, _, H, W = maps.shape
+    R = scenes.shape[0]
+    off = _ragged_offsets(counts, B, R, maps.device)
+    out = torch.empty((R, 3, H, W), dtype=torch.float32, device=maps.device)
+    with _on_device(maps.device):
+        _check(_ragged_binding().svbrdf_render_fwd_ragged(maps.data_ptr(), scenes.data_ptr(), off.data_ptr(),
+                                                          xrow(maps.device, W).data_ptr(), out.data_ptr(), B, R, H, W,
+                                                          _stream(maps.device)), "svbrdf_render_fwd_ragged")
+    return out
+
+
+def render_bwd_ragged(maps, scenes, counts, grad_out):
+    """K2, ragged: adjoint of render_fwd_ragged -> grad_maps [B,12,H,W] (zeros for a map without renders)."""
+    for t, name in ((maps, "maps"), (scenes, "scenes"), (grad_out, "grad_out")):
+        _require_device_f32(t, name)
+    maps, scenes, grad_out = maps.contiguous(), scenes.contiguous(), grad_out.contiguous()
+    B, _, H, W = maps.shape
+    R = scenes.shape[0]
+    if tuple(grad_out.shape) != (R, 3, H, W):
+        raise ValueError("grad_out must be [R,3,H,W]")
+    off = _ragged_offsets(counts, B, R, maps.device)
+    grad = torch.empty_like(maps)
+    with _on_device(maps.device):
+        _check(_ragged_binding().svbrdf_render_bwd_ragged(maps.data_ptr(), scenes.data_ptr(), off.data_ptr(),
+                                                          xrow(maps.device, W).data_ptr(), grad_out.data_ptr(),
+                                                          grad.data_ptr(), B, R, H, W, _stream(maps.device)),
+               "svbrdf_render_bwd_ragged")
+    return grad
+
+
 def rendering_loss(input, target, scenes, eps=0.1, want_grad=True, l1_weight=0.0, eps_l1=0.01, head=False):
     """K3: fused rendering loss (+ d loss/d input); with l1_weight != 0 the SVBRDF L1 loss is folded
     in (MixedLoss); with head=True `input` is the generator's [B,9,H,W] post-tanh output and the

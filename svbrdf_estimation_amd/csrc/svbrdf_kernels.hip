@@ -508,11 +508,14 @@ __device__ __forceinline__ void render_fwd_loop(const MapK mk[VEC], const float 
     }
 }
 
+// `offsets` (or null): ragged form, the renders of map b are rows offsets[b] .. offsets[b+1] of scenes / out
+// (any number per map, zero included) instead of the regular S per map.
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void k_render_fwd(const float *__restrict__ maps,
                                                          const float *__restrict__ scenes,
                                                          const float *__restrict__ xrow,
-                                                         float *__restrict__ out, int S, int H, int W)
+                                                         float *__restrict__ out, const int *__restrict__ offsets,
+                                                         int S, int H, int W)
 {
     const size_t plane = (size_t)H * W;
     const size_t pix = ((size_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
@@ -531,8 +534,13 @@ __global__ __launch_bounds__(kThreads) void k_render_fwd(const float *__restrict
     }
     float x[VEC], y;
     pixel_coords<VEC>(xrow, pix, W, x, y);
-    const float *__restrict__ scp = scenes + (size_t)b * S * 9;
-    float *__restrict__ o = out + (size_t)b * S * 3 * plane + pix;
+    size_t first = (size_t)b * S;
+    if (offsets) {
+        first = (size_t)offsets[b];
+        S = offsets[b + 1] - offsets[b];
+    }
+    const float *__restrict__ scp = scenes + first * 9;
+    float *__restrict__ o = out + first * 3 * plane + pix;
     if (__all(tied)) render_fwd_loop<VEC, 1>(mk, x, y, scp, o, plane, S);      // wave-uniform branch
     else render_fwd_loop<VEC, 3>(mk, x, y, scp, o, plane, S);
 }
@@ -571,7 +579,8 @@ __global__ __launch_bounds__(kThreads) void k_render_bwd(const float *__restrict
                                                          const float *__restrict__ scenes,
                                                          const float *__restrict__ xrow,
                                                          const float *__restrict__ grad_out,
-                                                         float *__restrict__ grad_maps, int S, int H, int W)
+                                                         float *__restrict__ grad_maps, const int *__restrict__ offsets,
+                                                         int S, int H, int W)
 {
     const size_t plane = (size_t)H * W;
     const size_t pix = ((size_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
@@ -593,8 +602,13 @@ __global__ __launch_bounds__(kThreads) void k_render_bwd(const float *__restrict
     Grad acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) zero_grad(acc[v]);
-    const float *__restrict__ scp = scenes + (size_t)b * S * 9;
-    const float *__restrict__ go = grad_out + (size_t)b * S * 3 * plane + pix;
+    size_t first = (size_t)b * S;
+    if (offsets) {
+        first = (size_t)offsets[b];
+        S = offsets[b + 1] - offsets[b];
+    }
+    const float *__restrict__ scp = scenes + first * 9;
+    const float *__restrict__ go = grad_out + first * 3 * plane + pix;
     if (__all(tied)) render_bwd_loop<VEC, 1>(mk, x, y, scp, go, plane, S, acc);
     else render_bwd_loop<VEC, 3>(mk, x, y, scp, go, plane, S, acc);
     store_grads<VEC, true>(grad_maps + (size_t)b * 12 * plane, plane, pix, acc);
@@ -1279,36 +1293,68 @@ int svbrdf_make_xrow(float *xrow_host, int W)
     return 0;
 }
 
-int svbrdf_render_fwd(const float *maps, const float *scenes, const float *xrow, float *out,
-                      int B, int S, int H, int W, void *stream)
+static int render_fwd_impl(const float *maps, const float *scenes, const float *xrow, float *out, const int *offsets,
+                           int B, int S, int H, int W, void *stream)
 {
     if (!maps || !scenes || !xrow || !out) return fail(SVBRDF_ERR_NULL, "render_fwd: null pointer");
     if (int e = check_dims(B, S, H, W)) return e;
-    if (!aligned(maps, 4) || !aligned(scenes, 4) || !aligned(xrow, 4) || !aligned(out, 4))
+    if (!aligned(maps, 4) || !aligned(scenes, 4) || !aligned(xrow, 4) || !aligned(out, 4) || !aligned(offsets, 4))
         return fail(SVBRDF_ERR_ALIGN, "render_fwd: pointers must be 4-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int vec = pick_vec(env_vec("SVBRDF_K1_VEC", 4), W, {maps, xrow, out});
     const dim3 grid = grid_for(B, H, W, vec), block(kThreads);
-    if (vec == 4) hipLaunchKernelGGL(k_render_fwd<4>, grid, block, 0, st, maps, scenes, xrow, out, S, H, W);
-    else if (vec == 2) hipLaunchKernelGGL(k_render_fwd<2>, grid, block, 0, st, maps, scenes, xrow, out, S, H, W);
-    else hipLaunchKernelGGL(k_render_fwd<1>, grid, block, 0, st, maps, scenes, xrow, out, S, H, W);
+    if (vec == 4) hipLaunchKernelGGL(k_render_fwd<4>, grid, block, 0, st, maps, scenes, xrow, out, offsets, S, H, W);
+    else if (vec == 2) hipLaunchKernelGGL(k_render_fwd<2>, grid, block, 0, st, maps, scenes, xrow, out, offsets, S, H, W);
+    else hipLaunchKernelGGL(k_render_fwd<1>, grid, block, 0, st, maps, scenes, xrow, out, offsets, S, H, W);
     return launch_status("render_fwd launch");
+}
+
+int svbrdf_render_fwd(const float *maps, const float *scenes, const float *xrow, float *out,
+                      int B, int S, int H, int W, void *stream)
+{
+    return render_fwd_impl(maps, scenes, xrow, out, nullptr, B, S, H, W, stream);
+}
+
+int svbrdf_render_fwd_ragged(const float *maps, const float *scenes, const int *offsets, const float *xrow, float *out,
+                             int B, int R, int H, int W, void *stream)
+{
+    if (!offsets) return fail(SVBRDF_ERR_NULL, "render_fwd_ragged: offsets is null");
+    if (R < 0) return fail(SVBRDF_ERR_DIMS, "render_fwd_ragged: R must be >= 0");
+    if (R == 0) return check_dims(B, 1, H, W);          // nothing to render
+    return render_fwd_impl(maps, scenes, xrow, out, offsets, B, 1, H, W, stream);
+}
+
+static int render_bwd_impl(const float *maps, const float *scenes, const float *xrow, const float *grad_out,
+                           float *grad_maps, const int *offsets, int B, int S, int H, int W, void *stream)
+{
+    if (!maps || !scenes || !xrow || !grad_out || !grad_maps) return fail(SVBRDF_ERR_NULL, "render_bwd: null pointer");
+    if (int e = check_dims(B, S, H, W)) return e;
+    if (!aligned(maps, 4) || !aligned(scenes, 4) || !aligned(xrow, 4) || !aligned(grad_out, 4) || !aligned(grad_maps, 4) ||
+        !aligned(offsets, 4))
+        return fail(SVBRDF_ERR_ALIGN, "render_bwd: pointers must be 4-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int vec = pick_vec(env_vec("SVBRDF_K2_VEC", 2), W, {maps, xrow, grad_out, grad_maps});
+    const dim3 grid = grid_for(B, H, W, vec), block(kThreads);
+    if (vec == 4) hipLaunchKernelGGL(k_render_bwd<4>, grid, block, 0, st, maps, scenes, xrow, grad_out, grad_maps, offsets, S, H, W);
+    else if (vec == 2) hipLaunchKernelGGL(k_render_bwd<2>, grid, block, 0, st, maps, scenes, xrow, grad_out, grad_maps, offsets, S, H, W);
+    else hipLaunchKernelGGL(k_render_bwd<1>, grid, block, 0, st, maps, scenes, xrow, grad_out, grad_maps, offsets, S, H, W);
+    return launch_status("render_bwd launch");
 }
 
 int svbrdf_render_bwd(const float *maps, const float *scenes, const float *xrow, const float *grad_out,
                       float *grad_maps, int B, int S, int H, int W, void *stream)
 {
-    if (!maps || !scenes || !xrow || !grad_out || !grad_maps) return fail(SVBRDF_ERR_NULL, "render_bwd: null pointer");
-    if (int e = check_dims(B, S, H, W)) return e;
-    if (!aligned(maps, 4) || !aligned(scenes, 4) || !aligned(xrow, 4) || !aligned(grad_out, 4) || !aligned(grad_maps, 4))
-        return fail(SVBRDF_ERR_ALIGN, "render_bwd: pointers must be 4-byte aligned");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int vec = pick_vec(env_vec("SVBRDF_K2_VEC", 2), W, {maps, xrow, grad_out, grad_maps});
-    const dim3 grid = grid_for(B, H, W, vec), block(kThreads);
-    if (vec == 4) hipLaunchKernelGGL(k_render_bwd<4>, grid, block, 0, st, maps, scenes, xrow, grad_out, grad_maps, S, H, W);
-    else if (vec == 2) hipLaunchKernelGGL(k_render_bwd<2>, grid, block, 0, st, maps, scenes, xrow, grad_out, grad_maps, S, H, W);
-    else hipLaunchKernelGGL(k_render_bwd<1>, grid, block, 0, st, maps, scenes, xrow, grad_out, grad_maps, S, H, W);
-    return launch_status("render_bwd launch");
+    return render_bwd_impl(maps, scenes, xrow, grad_out, grad_maps, nullptr, B, S, H, W, stream);
+}
+
+int svbrdf_render_bwd_ragged(const float *maps, const float *scenes, const int *offsets, const float *xrow,
+                             const float *grad_out, float *grad_maps, int B, int R, int H, int W, void *stream)
+{
+    if (!offsets) return fail(SVBRDF_ERR_NULL, "render_bwd_ragged: offsets is null");
+    if (R < 0) return fail(SVBRDF_ERR_DIMS, "render_bwd_ragged: R must be >= 0");
+    // R == 0 still launches: every map's gradient is written (zeros)
+    const float *go = (R == 0 && !grad_out) ? maps : grad_out, *sc = (R == 0 && !scenes) ? maps : scenes;
+    return render_bwd_impl(maps, sc, xrow, go, grad_maps, offsets, B, 1, H, W, stream);
 }
 
 size_t svbrdf_rendering_loss_workspace_bytes(int B, int S, int H, int W)

@@ -96,6 +96,66 @@ def test_device_division_and_sqrt_are_correctly_rounded(dev, native):
     assert counts.tolist() == [0, 0], "mismatches vs IEEE (div, sqrt): %s" % counts.tolist()
 
 
+def test_ragged_render_entry_points(dev, native, oracle):
+    """SURVEY 8b's "R (map, scene) pairs in one launch": svbrdf_render_{fwd,bwd}_ragged with a different number of
+    renders per map (zero included) against the oracle map by map, and against the regular entry points when every
+    map has the same count (bitwise)."""
+    from svbrdf_estimation_amd import environment
+    B, H = 4, 40
+    counts = [2, 0, 5, 1]
+    maps = synth.make_maps(31, B, H, tiled_roughness=False)
+    maps[2] = synth.make_maps(32, 1, H)[0]                      # one tied-roughness map among untied ones
+    torch.manual_seed(12)
+    scenes = torch.cat([environment.scene_table(c, 0) if c < 3 else environment.scene_table(2, c - 2) for c in counts if c]).numpy()
+    R = sum(counts)
+    out = _np(native.render_fwd_ragged(_t(maps, dev), _t(scenes, dev), counts))
+    cot = synth.uniform01(33, (R, 3, H, H)) - np.float32(0.5)
+    grad = _np(native.render_bwd_ragged(_t(maps, dev), _t(scenes, dev), counts, _t(cot, dev)))
+    r0 = 0
+    for b, c in enumerate(counts):
+        if c == 0:
+            assert not grad[b].any()
+            continue
+        tab = scenes[None, r0:r0 + c]
+        assert_render_strict(out[r0:r0 + c], oracle.render_fwd(maps[b:b + 1], tab)[0], "ragged fwd map %d" % b)
+        assert_grad_close(grad[b:b + 1], oracle.render_bwd(maps[b:b + 1], tab, cot[None, r0:r0 + c]), "ragged bwd map %d" % b)
+        r0 += c
+    # uniform counts == the regular entry points, bit for bit
+    S = 3
+    torch.manual_seed(13)
+    table = torch.stack([environment.scene_table(1, 2) for _ in range(B)])
+    reg = native.render_fwd(_t(maps, dev), table.to(dev))
+    rag = native.render_fwd_ragged(_t(maps, dev), table.reshape(B * S, 9).to(dev), [S] * B)
+    assert torch.equal(reg.reshape(B * S, 3, H, H), rag)
+    cot2 = _t(synth.uniform01(34, (B, S, 3, H, H)) - np.float32(0.5), dev)
+    assert torch.equal(native.render_bwd(_t(maps, dev), table.to(dev), cot2),
+                       native.render_bwd_ragged(_t(maps, dev), table.reshape(B * S, 9).to(dev), [S] * B, cot2.reshape(B * S, 3, H, H)))
+    lib = native._load()
+    p = reg.data_ptr()
+    assert lib.svbrdf_render_fwd_ragged(p, p, None, p, p, 1, 1, 4, 4, None) == -1
+    with pytest.raises(ValueError):
+        native.render_fwd_ragged(_t(maps, dev), _t(scenes, dev), [1, 1, 1, 1])
+
+
+def test_c_host_program_calls_the_abi(dev, golden, tmp_path):
+    """a plain-C host (tests/c_host/render_host.c: gcc, the HIP runtime's C API, include/svbrdf_hip.h and nothing else)
+    renders the KAT-1 case through svbrdf_render_fwd and prints the radiance; it must be the reference's value
+    (within the rendering tolerance: the kernels are a few ULP from the reference's own rounding)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "render_host")
+    libdir = os.path.join(root, "svbrdf_estimation_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "c_host", "render_host.c"),
+                           "-o", exe, "-L" + libdir, "-lsvbrdf_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    vals = np.array([float(v) for v in out.stdout.split()[-12:]], np.float32).reshape(3, 2, 2)
+    g = golden("g9_kat.npz")
+    assert_render_strict(vals, g["kat1_out"][0], "C host KAT-1")
+
+
 # ---------------------------------------------------------------- K1 / K2 vs oracle and goldens
 
 @pytest.mark.parametrize("name", ["g1_render_64.npz", "g1_render_32_tiled.npz"])
@@ -771,6 +831,11 @@ def test_config4_batch16_mixed_loss_module_path(dev, native, oracle):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.skipif(not os.environ.get("SVBRDF_SLOW_TESTS"),
+                    reason="~5 min on a fresh box, nearly all of it MIOpen compiling convolution kernels for the 80-image "
+                           "batch (stock PyTorch-ROCm, outside the hot path); run with SVBRDF_SLOW_TESTS=1 -- the last run's "
+                           "output is committed as profiles/r02_config4_train.json.  The loss kernels at this configuration "
+                           "are covered by test_config4_batch16_mixed_loss_module_path, which always runs")
 def test_config4_training_harness_multi_view_5_batch_16(dev):
     """configs[3] through train.py: multi-view network (N = 5 photos, pooled encoder, models.py:348-411), batch 16,
     mixed loss, photos synthesised on the GPU -- a few steps at size"""
@@ -851,7 +916,7 @@ def test_unet_forward_equals_reference_fixture_on_the_gpu(dev, golden, tag):
     """the re-stated network on the MIOpen path against the reference's forward pass (regenerated weights, fixture
     g13): what test_training_models.py can only check where the reference is mounted"""
     from test_dataset_golden import unet_against_fixture
-    err = unet_against_fixture(golden, tag, dev, rtol=1e-3, atol=3e-4)
+    err = unet_against_fixture(golden, tag, dev, rtol=1e-4, atol=1e-4)     # measured: 5e-6 / 1.2e-5 max abs error
     print("U-Net %s on the GPU vs reference fixture: max abs err %.2e" % (tag, err))
 
 

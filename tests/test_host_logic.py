@@ -268,3 +268,26 @@ def test_committed_bench_line_follows_the_contract():
         assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == j["unit"] and c["sample"]
         # the number is consistent with its own step time
         assert abs(j["value"] - j["config"]["global_batch"] / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+
+
+def test_header_is_valid_c_and_the_c_host_builds(tmp_path):
+    """include/svbrdf_hip.h must be consumable by a C compiler (the boundary is a C ABI): compiled alone as strict
+    C99, every declared function referenced; and the plain-C host program of the GPU suite must build and link"""
+    import re
+    import subprocess
+    header = os.path.join(ROOT, "include", "svbrdf_hip.h")
+    names = sorted(set(re.findall(r"\b(svbrdf_\w+)\s*\(", open(header).read())))
+    assert len(names) >= 17
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "svbrdf_hip.h"\n#include <stddef.h>\n'
+                   "typedef void (*fn)(void);\n"
+                   "fn table[] = {%s};\nint main(void) { return table[0] == NULL; }\n"
+                   % ", ".join("(fn)%s" % n for n in names))
+    lib = os.path.join(ROOT, "svbrdf_estimation_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-Wno-pedantic-ms-format",
+                           "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "use_header"),
+                           "-L" + lib, "-lsvbrdf_hip", "-Wl,-rpath," + lib, "-Wl,--allow-shlib-undefined"])
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_host", "render_host.c"),
+                           "-o", str(tmp_path / "render_host"), "-L" + lib, "-lsvbrdf_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
