@@ -35,18 +35,22 @@
 
 #include "svbrdf_hip.h"
 
-// Translation units.  The scheduler options that suit the forward+adjoint variants of the fused loss kernel (no
-// post-RA scheduling, max-memory-clause strategy: -6 ... -14 % on them) cost the HBM-bound K2 13 % and the
-// forward-only loss kernels 6 %, which prefer a bottom-up post-RA scheduler (measured).  The
-// Makefile therefore compiles this file twice and links both objects into libsvbrdf_hip.so:
-//   SVBRDF_TU=0  everything except the forward+adjoint loss kernels
-//   SVBRDF_TU=1  only those kernels and their launcher
+// Translation units.  The order the compiler leaves the instructions in moves these VALU-bound kernels by up to 20 %
+// at an identical instruction mix, and no single set of LLVM scheduler options suits every kernel (measured grid:
+// csrc/Makefile, profiles/r02_sched_grid.txt).  The Makefile therefore compiles this file three times and links the
+// objects into libsvbrdf_hip.so:
+//   SVBRDF_TU=0  everything except the forward+adjoint loss kernels        (bottom-up post-RA scheduler)
+//   SVBRDF_TU=1  the forward+adjoint RenderingLoss kernels <GRAD, L1=0, HEAD=0> and their launcher
+//                                                                         (no post-RA scheduler, max-memory-clause)
+//   SVBRDF_TU=3  the forward+adjoint MixedLoss / head-fused kernels (L1 or HEAD set) and their launcher
+//                                                                         (no post-RA scheduler, iterative-minreg)
 // SVBRDF_TU=2 (default; tools/ build the file with one command): everything in one unit.
 #ifndef SVBRDF_TU
 #define SVBRDF_TU 2
 #endif
-#define SVBRDF_TU_MAIN (SVBRDF_TU != 1)
-#define SVBRDF_TU_ADJOINT (SVBRDF_TU != 0)
+#define SVBRDF_TU_MAIN (SVBRDF_TU == 0 || SVBRDF_TU == 2)
+#define SVBRDF_TU_ADJOINT_PLAIN (SVBRDF_TU == 1 || SVBRDF_TU == 2)
+#define SVBRDF_TU_ADJOINT_EXTRA (SVBRDF_TU == 3 || SVBRDF_TU == 2)
 
 namespace {
 
@@ -704,6 +708,78 @@ __device__ __forceinline__ void loss_pixel_scene(const VConst &K, const Geom &g,
     }
 }
 
+// The same for independent roughness channels (three lobes per map), one colour channel after the other: target lobe,
+// input lobe, loss term and adjoint of channel k are finished before channel k+1 starts, so that only the four sums
+// over the lobes (d loss/d VN, LN, NH^2, LN+) stay live between channels.  The joint form above keeps three lobes'
+// partials (15 values) and three F/f pairs alive across the loss term and cost the three-lobe loop 19 scratch
+// accesses and ~60 register moves per iteration (510 VALU; 77.8 us at config 2).  Price: the three 1/(render+eps)
+// are three v_rcp here instead of one.
+template <bool WITH_GRAD>
+__device__ __forceinline__ void loss_pixel_scene_by_channel(const VConst &K, const Geom &g, const MapK &mi, const MapK &mt,
+                                                            float eps, float inv_count, float &lsum, Grad &acc)
+{
+    const Dots dt = dots(K, g, mt);
+    const Dots di = dots(K, g, mi);
+    constexpr float c = 9.765625e-04f;               // 2^-10, as in loss_pixel_scene
+    const float ec = eps * c, nc = inv_count * c;
+    const float omp = 1.0f - g.p;
+    float g_LNp = 0.0f, g_VN = 0.0f, g_LN = 0.0f, sN = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const Lobe lt = lobe<false>(K, mt.A[k], mt.oA[k], dt);
+        const float Ft = fma_(mt.oms[k], g.p, mt.s[k]);
+        const float ft = fma_(1.0f - Ft, mt.dpi[k], Ft * lt.GD);
+        const float rt = ft * (g.E[k] * dt.LNp);
+        const Lobe li = lobe<WITH_GRAD>(K, mi.A[k], mi.oA[k], di);
+        const float Fi = fma_(mi.oms[k], g.p, mi.s[k]);
+        const float fi = fma_(1.0f - Fi, mi.dpi[k], Fi * li.GD);
+        const float ri = fi * (g.E[k] * di.LNp);
+        const float b = fma_(ri, c, ec), bt = fma_(rt, c, ec);
+        const float ib = rcp_(b);
+        const float delta = (b == bt) ? 0.0f : -K.ln2 * log2_(bt * ib);
+        lsum += fabsf(delta);
+        if (WITH_GRAD) {
+            const float sg = __builtin_amdgcn_fmed3f(delta * K.huge, -1.0f, 1.0f);
+            const float g_rad = sg * (nc * ib);
+            const float gE = g_rad * g.E[k];
+            const float g_f = gE * di.LNp;
+            g_LNp = fma_(gE, fi, g_LNp);
+            const float g_F = fma_(g_f, li.GD, -(g_f * mi.dpi[k]));
+            acc.s[k] = fma_(g_F, omp, acc.s[k]);
+            acc.d[k] = fma_(g_f * (1.0f - Fi), K.inv_pi, acc.d[k]);
+            const float gGD = g_f * Fi;
+            acc.r[k] = fma_(gGD * li.KA, mi.r4m[k], acc.r[k]);
+            g_VN = fma_(gGD, li.KV, g_VN);
+            g_LN = fma_(gGD, li.KL, g_LN);
+            sN = fma_(gGD, li.KN, sN);
+        }
+    }
+    if (WITH_GRAD) {
+        float g_NH = (sN * 2.0f) * di.NH;
+        if (!(di.nh_raw >= K.tiny)) g_NH = 0.0f;
+        if (!(di.vn_raw >= K.tiny)) g_VN = 0.0f;
+        if (!(di.ln_raw >= K.tiny)) g_LN = 0.0f;
+        if (!(di.ln_raw >= 0.0f)) g_LNp = 0.0f;
+        const float gl = g_LN + g_LNp;
+        acc.n[0] = fma_(g_NH, g.hx, fma_(g_VN, g.wox, fma_(gl, g.wix, acc.n[0])));
+        acc.n[1] = fma_(g_NH, g.hy, fma_(g_VN, g.woy, fma_(gl, g.wiy, acc.n[1])));
+        acc.n[2] = fma_(g_NH, g.hz, fma_(g_VN, g.woz, fma_(gl, g.wiz, acc.n[2])));
+    }
+}
+
+#ifndef SVBRDF_UNTIED_BY_CHANNEL
+#define SVBRDF_UNTIED_BY_CHANNEL 1
+#endif
+template <int NL, bool WITH_GRAD>
+__device__ __forceinline__ void loss_pixel_scene_any(const VConst &K, const Geom &g, const MapK &mi, const MapK &mt,
+                                                     float eps, float inv_count, float &lsum, Grad &acc)
+{
+    if (NL == 3 && SVBRDF_UNTIED_BY_CHANNEL && SVBRDF_ABLATE == 0)
+        loss_pixel_scene_by_channel<WITH_GRAD>(K, g, mi, mt, eps, inv_count, lsum, acc);
+    else
+        loss_pixel_scene<NL, WITH_GRAD>(K, g, mi, mt, eps, inv_count, lsum, acc);
+}
+
 // Scene loop of K3, software-pipelined: the geometry of render s+1 (three rsq-headed dependent
 // chains: lengths -> reciprocals -> quotients) is computed in the same iteration as the
 // shading / loss / adjoint of render s.  The two are independent instruction streams, which gives
@@ -745,7 +821,7 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt,
             __builtin_amdgcn_sched_barrier(0);
             // two independent streams from here to the end of the iteration:
             g_next = geometry(K, cur, x, y);                     // render s+1 (a harmless repeat on the last pass)
-            loss_pixel_scene<NL, WITH_GRAD>(K, g, mi, mt, eps, inv_count, lsum, acc);
+            loss_pixel_scene_any<NL, WITH_GRAD>(K, g, mi, mt, eps, inv_count, lsum, acc);
         }
     } else {
         load_scene(sc_lds, sc);
@@ -754,7 +830,7 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt,
             const Geom g = g_next;
             load_scene(sc_lds + (s + 1 < S ? s + 1 : s) * 9, sc);
             g_next = geometry(K, sc, x, y);
-            loss_pixel_scene<NL, WITH_GRAD>(K, g, mi, mt, eps, inv_count, lsum, acc);
+            loss_pixel_scene_any<NL, WITH_GRAD>(K, g, mi, mt, eps, inv_count, lsum, acc);
         }
     }
 #if SVBRDF_TIMING
@@ -1228,8 +1304,10 @@ dim3 grid_for(int B, int H, int W, int vec)
 #endif  // SVBRDF_TU_MAIN
 
 
-// launches one K3 variant; `rows` = the host scene table for the by-value kernels (NULL: device table `scenes`)
-template <bool G>
+// launches one K3 variant; `rows` = the host scene table for the by-value kernels (NULL: device table `scenes`).
+// WHICH selects the variants this translation unit instantiates: 0 = <G, L1=0, HEAD=0> only, 1 = the other three,
+// 2 = all four.
+template <bool G, int WHICH>
 void launch_k3(bool with_l1, bool head, const float *rows, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st,
                const float *input, const float *target, const float *scenes, const float *xrow, float eps,
                float inv_count, double loss_scale, float fixed_scale, L1Params l1, float *grad_input,
@@ -1248,29 +1326,40 @@ void launch_k3(bool with_l1, bool head, const float *rows, dim3 grid, dim3 block
                                xrow, eps, inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, S,  \
                                H, W);                                                                           \
     } while (0)
-    if (head) { if (with_l1) SVBRDF_LAUNCH_K3(true, true); else SVBRDF_LAUNCH_K3(false, true); }
-    else { if (with_l1) SVBRDF_LAUNCH_K3(true, false); else SVBRDF_LAUNCH_K3(false, false); }
+    if constexpr (WHICH != 0) {
+        if (head) { if (with_l1) SVBRDF_LAUNCH_K3(true, true); else SVBRDF_LAUNCH_K3(false, true); }
+        else if (with_l1) SVBRDF_LAUNCH_K3(true, false);
+    }
+    if constexpr (WHICH != 1) {
+        if (!head && !with_l1) SVBRDF_LAUNCH_K3(false, false);
+    }
 #undef SVBRDF_LAUNCH_K3
 }
 
 }  // namespace
 
-// the forward+adjoint variants live in their own translation unit (see the top of this file)
-extern "C" __attribute__((visibility("hidden"))) void svbrdf_internal_launch_k3_adjoint(
-    int with_l1, int head, const float *rows, unsigned gx, unsigned gy, size_t lds_bytes, void *stream, const float *input,
-    const float *target, const float *scenes, const float *xrow, float eps, float inv_count, double loss_scale,
-    float fixed_scale, float l1_sum_scale, float l1_grad_scale, float l1_eps, float *grad_input, unsigned long long *ws,
-    float *loss_out, int B, int S, int H, int W);
-#if SVBRDF_TU_ADJOINT
-void svbrdf_internal_launch_k3_adjoint(int with_l1, int head, const float *rows, unsigned gx, unsigned gy, size_t lds_bytes,
-                                       void *stream, const float *input, const float *target, const float *scenes,
-                                       const float *xrow, float eps, float inv_count, double loss_scale, float fixed_scale,
-                                       float l1_sum_scale, float l1_grad_scale, float l1_eps, float *grad_input,
-                                       unsigned long long *ws, float *loss_out, int B, int S, int H, int W)
+// the forward+adjoint variants live in their own translation units (see the top of this file)
+#define SVBRDF_K3_ADJOINT_ARGS                                                                                        \
+    int with_l1, int head, const float *rows, unsigned gx, unsigned gy, size_t lds_bytes, void *stream,                 \
+        const float *input, const float *target, const float *scenes, const float *xrow, float eps, float inv_count,   \
+        double loss_scale, float fixed_scale, float l1_sum_scale, float l1_grad_scale, float l1_eps, float *grad_input, \
+        unsigned long long *ws, float *loss_out, int B, int S, int H, int W
+extern "C" __attribute__((visibility("hidden"))) void svbrdf_internal_launch_k3_adjoint_plain(SVBRDF_K3_ADJOINT_ARGS);
+extern "C" __attribute__((visibility("hidden"))) void svbrdf_internal_launch_k3_adjoint_extra(SVBRDF_K3_ADJOINT_ARGS);
+#if SVBRDF_TU_ADJOINT_PLAIN
+void svbrdf_internal_launch_k3_adjoint_plain(SVBRDF_K3_ADJOINT_ARGS)
 {
-    launch_k3<true>(with_l1 != 0, head != 0, rows, dim3(gx, gy, 1), dim3(kLossThreads), lds_bytes,
-                    static_cast<hipStream_t>(stream), input, target, scenes, xrow, eps, inv_count, loss_scale, fixed_scale,
-                    L1Params{l1_sum_scale, l1_grad_scale, l1_eps}, grad_input, ws, loss_out, B, S, H, W);
+    launch_k3<true, 0>(with_l1 != 0, head != 0, rows, dim3(gx, gy, 1), dim3(kLossThreads), lds_bytes,
+                       static_cast<hipStream_t>(stream), input, target, scenes, xrow, eps, inv_count, loss_scale, fixed_scale,
+                       L1Params{l1_sum_scale, l1_grad_scale, l1_eps}, grad_input, ws, loss_out, B, S, H, W);
+}
+#endif
+#if SVBRDF_TU_ADJOINT_EXTRA
+void svbrdf_internal_launch_k3_adjoint_extra(SVBRDF_K3_ADJOINT_ARGS)
+{
+    launch_k3<true, 1>(with_l1 != 0, head != 0, rows, dim3(gx, gy, 1), dim3(kLossThreads), lds_bytes,
+                       static_cast<hipStream_t>(stream), input, target, scenes, xrow, eps, inv_count, loss_scale, fixed_scale,
+                       L1Params{l1_sum_scale, l1_grad_scale, l1_eps}, grad_input, ws, loss_out, B, S, H, W);
 }
 #endif
 
@@ -1401,12 +1490,12 @@ static int loss_impl(const char *who, bool head, bool scenes_on_host, const floa
     const L1Params l1{l1_weight * (float)S, (float)((double)l1_weight / ((double)B * 3.0 * (double)plane)), eps_l1};
     const float *rows = scenes_on_host ? scenes : nullptr;
     if (grad_input)
-        svbrdf_internal_launch_k3_adjoint(l1_weight != 0.0f, head, rows, grid.x, grid.y, lds_bytes, stream, input, target,
-                                          scenes, xrow, eps, inv_count, loss_scale, fixed_scale, l1.sum_scale,
-                                          l1.grad_scale, l1.eps, grad_input, ws, loss_out, B, S, H, W);
+        (l1_weight != 0.0f || head ? svbrdf_internal_launch_k3_adjoint_extra : svbrdf_internal_launch_k3_adjoint_plain)(
+            l1_weight != 0.0f, head, rows, grid.x, grid.y, lds_bytes, stream, input, target, scenes, xrow, eps, inv_count,
+            loss_scale, fixed_scale, l1.sum_scale, l1.grad_scale, l1.eps, grad_input, ws, loss_out, B, S, H, W);
     else
-        launch_k3<false>(l1_weight != 0.0f, head, rows, grid, block, lds_bytes, st, input, target, scenes, xrow, eps,
-                         inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, B, S, H, W);
+        launch_k3<false, 2>(l1_weight != 0.0f, head, rows, grid, block, lds_bytes, st, input, target, scenes, xrow, eps,
+                            inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, B, S, H, W);
     return launch_status(who);
 }
 

@@ -2,13 +2,13 @@
 
 The last ~10 % of K3's speed comes from per-translation-unit LLVM scheduler options and from algebra that removed
 transcendentals; nothing at run time would notice a toolchain bump or an innocent edit undoing either.  This test
-compiles the adjoint translation unit to assembly with the Makefile's own flags and checks the headline kernel
-k_rendering_loss_inl<GRAD=1,L1=0,HEAD=0> instruction by instruction:
+compiles the two forward+adjoint translation units to assembly with the Makefile's own flags and checks the headline
+kernel k_rendering_loss_inl<GRAD=1,L1=0,HEAD=0> (and, more loosely, the MixedLoss / head-fused variants):
 
-  * target gfx950, 4 waves/SIMD (<= 128 VGPRs), no AGPRs
+  * target gfx950, 4 waves/SIMD (<= 128 VGPRs), no AGPRs, no scratch at all in the headline kernel
   * tied-roughness scene loop: VALU count within the budget, exactly 13 transcendentals, no scratch traffic,
     no IEEE-division expansion (v_div_*), no packed math (the build uses -fno-slp-vectorize on purpose)
-  * three-lobe (untied) scene loop: transcendental count, bounded scratch traffic
+  * three-lobe (untied) scene loop: VALU and transcendental count, no scratch traffic
   * numerics contract: the products of the exact dot products on the coords -> NH path are never contracted into
     FMAs: every dot3 must appear as 3 v_mul + 2 v_add; checked on the stand-alone `svbrdf_isa_probe_dot3` kernel
     and by counting the plain multiplies/adds of the loop against the FMA count.
@@ -26,11 +26,13 @@ CSRC = os.path.join(ROOT, "svbrdf_estimation_amd", "csrc")
 HEADLINE = "k_rendering_loss_inlILb1ELb0ELb0"
 
 # budgets: measured values of the shipped build + a small margin (tools/isa_stats.py prints the current ones)
-TIED_LOOP_VALU_MAX = 340
+TIED_LOOP_VALU_MAX = 342
 TIED_LOOP_TRANS = 13
-UNTIED_LOOP_VALU_MAX = 520
-UNTIED_LOOP_TRANS = 25
-UNTIED_LOOP_SCRATCH_MAX = 24
+UNTIED_LOOP_VALU_MAX = 460           # RenderingLoss kernel: 451 (three lobes, channel by channel)
+UNTIED_LOOP_TRANS = 27
+UNTIED_EXTRA_VALU_MAX = {"mixed": 510, "head": 375}     # MixedLoss 498; head-fused 368 (input tied by construction)
+UNTIED_EXTRA_TRANS = {"mixed": 27, "head": 21}
+UNTIED_EXTRA_SCRATCH_MAX = {"mixed": 10, "head": 0}
 
 
 def _make_var(name):
@@ -38,16 +40,26 @@ def _make_var(name):
     return out.strip().split()
 
 
-@pytest.fixture(scope="module")
-def adjoint_asm(tmp_path_factory):
-    d = tmp_path_factory.mktemp("isa")
-    out = str(d / "adjoint.s")
-    cmd = (_make_var("HIPCC") + _make_var("HIPFLAGS") + _make_var("SCHED_ADJOINT") +
-           ["-DSVBRDF_TU=1", "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "svbrdf_kernels.hip")])
+def _compile_tu(tmp, tu, sched_var):
+    out = str(tmp / ("tu%d.s" % tu))
+    cmd = (_make_var("HIPCC") + _make_var("HIPFLAGS") + _make_var(sched_var) +
+           ["-DSVBRDF_TU=%d" % tu, "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "svbrdf_kernels.hip")])
     cmd = [c.replace("../../include", os.path.join(ROOT, "include")) for c in cmd]
     subprocess.check_call(cmd, cwd=CSRC, stderr=subprocess.DEVNULL)
     with open(out) as f:
         return f.read()
+
+
+@pytest.fixture(scope="module")
+def adjoint_asm(tmp_path_factory):
+    """assembly of the RenderingLoss forward+adjoint translation unit (SVBRDF_TU=1), the Makefile's own flags"""
+    return _compile_tu(tmp_path_factory.mktemp("isa1"), 1, "SCHED_ADJOINT")
+
+
+@pytest.fixture(scope="module")
+def adjoint_extra_asm(tmp_path_factory):
+    """assembly of the MixedLoss / head-fused forward+adjoint translation unit (SVBRDF_TU=3)"""
+    return _compile_tu(tmp_path_factory.mktemp("isa3"), 3, "SCHED_ADJOINT_EXTRA")
 
 
 def test_headline_kernel_resources(adjoint_asm):
@@ -56,38 +68,43 @@ def test_headline_kernel_resources(adjoint_asm):
     name, meta, whole, loops, ins, rng = isa_stats.analyse(adjoint_asm, HEADLINE)
     assert int(meta["NumVgprs"]) <= 128 and int(meta["NumAgprs"]) == 0, meta
     assert int(meta["Occupancy"]) >= 4, meta
+    assert int(meta["ScratchSize"]) == 0 and whole["scratch"] == 0, (meta, whole)      # no spill anywhere in the kernel
     assert whole["v_div"] == 0 and whole["v_pk"] == 0, whole
     print("headline kernel: %s" % {k: meta[k] for k in ("NumVgprs", "TotalNumSgprs", "ScratchSize", "Occupancy")})
 
 
 def test_scene_loops_instruction_budget(adjoint_asm):
     import isa_stats
-    name, meta, whole, loops, ins, rng = isa_stats.analyse(adjoint_asm, HEADLINE)
-    assert len(loops) == 2, "expected the three-lobe and the tied scene loop, found %d loops" % len(loops)
-    untied, tied = sorted(loops, key=lambda c: -c["valu"])
-    print("tied loop: %s" % tied)
-    print("untied loop: %s" % untied)
-    assert tied["trans"] == TIED_LOOP_TRANS, tied
-    assert tied["valu"] <= TIED_LOOP_VALU_MAX, tied
-    assert tied["scratch"] == 0 and tied["vmem"] == 0 and tied["lds"] == 0, tied
-    assert tied["v_div"] == 0 and tied["v_pk"] == 0, tied
-    assert untied["trans"] == UNTIED_LOOP_TRANS, untied
-    assert untied["valu"] <= UNTIED_LOOP_VALU_MAX, untied
-    assert untied["scratch"] <= UNTIED_LOOP_SCRATCH_MAX and untied["v_div"] == 0, untied
-
-
-def test_every_adjoint_variant_tied_loop_budget(adjoint_asm):
-    import isa_stats
     names = [k for k in isa_stats.kernels(adjoint_asm) if "k_rendering_loss" in k]
-    assert len(names) == 8, names            # {by-value, device table} x {L1} x {HEAD}
+    assert len(names) == 2, names            # by-value scene table and device scene table
     for k in names:
-        _, meta, whole, loops, _, _ = isa_stats.analyse(adjoint_asm, k)
-        assert int(meta["NumVgprs"]) <= 128, (k, meta)
-        assert whole["v_div"] == 0, k
-        tied = min(loops, key=lambda c: c["valu"])
-        with_l1 = "Lb1ELb1E" in k           # <GRAD=1, L1=1, ...>: the L1 accumulators cost the loop up to two spill slots
-        assert tied["scratch"] <= (2 if with_l1 else 0), (k, tied)
-        assert tied["trans"] == TIED_LOOP_TRANS and tied["valu"] <= TIED_LOOP_VALU_MAX, (k, tied)
+        name, meta, whole, loops, ins, rng = isa_stats.analyse(adjoint_asm, k)
+        assert len(loops) == 2, "expected the three-lobe and the tied scene loop, found %d loops" % len(loops)
+        untied, tied = sorted(loops, key=lambda c: -c["valu"])
+        print("tied loop: %s" % tied)
+        print("untied loop: %s" % untied)
+        assert tied["trans"] == TIED_LOOP_TRANS, tied
+        assert tied["valu"] <= TIED_LOOP_VALU_MAX, tied
+        assert tied["scratch"] == 0 and tied["vmem"] == 0 and tied["lds"] == 0, tied
+        assert tied["v_div"] == 0 and tied["v_pk"] == 0, tied
+        assert untied["trans"] == UNTIED_LOOP_TRANS, untied
+        assert untied["valu"] <= UNTIED_LOOP_VALU_MAX, untied
+        assert untied["scratch"] == 0 and untied["v_div"] == 0, untied
+
+
+def test_mixed_and_head_fused_variants_budget(adjoint_extra_asm):
+    import isa_stats
+    names = [k for k in isa_stats.kernels(adjoint_extra_asm) if "k_rendering_loss" in k]
+    assert len(names) == 6, names            # {by-value, device table} x {L1 only, HEAD only, HEAD + L1}
+    for k in names:
+        _, meta, whole, loops, _, _ = isa_stats.analyse(adjoint_extra_asm, k)
+        assert int(meta["NumVgprs"]) <= 128 and int(meta["Occupancy"]) >= 4, (k, meta)
+        assert whole["v_div"] == 0 and whole["v_pk"] == 0, k
+        untied, tied = sorted(loops, key=lambda c: -c["valu"])
+        kind = "head" if k.endswith("Lb1EEEvNS_10SceneBlockEPKfS3_S3_ffdfNS_8L1ParamsEPfPyS5_iii") or "ELb1EEEvPKf" in k else "mixed"
+        assert tied["scratch"] == 0 and tied["trans"] == TIED_LOOP_TRANS and tied["valu"] <= TIED_LOOP_VALU_MAX, (k, tied)
+        assert untied["trans"] == UNTIED_EXTRA_TRANS[kind] and untied["valu"] <= UNTIED_EXTRA_VALU_MAX[kind], (k, kind, untied)
+        assert untied["scratch"] <= UNTIED_EXTRA_SCRATCH_MAX[kind], (k, kind, untied)
 
 
 def test_dot_products_are_not_contracted(tmp_path):

@@ -16,7 +16,7 @@
 // the library under test is chosen at run time (same-box A/B of builds): bind the four entry points used by name
 static decltype(&svbrdf_make_xrow) p_make_xrow;
 static decltype(&svbrdf_rendering_loss_workspace_bytes) p_ws_bytes;
-static decltype(&svbrdf_mixed_loss_fwd_bwd_host_scenes) p_loss;
+static decltype(&svbrdf_mixed_loss_fwd_bwd_host_scenes) p_loss, p_head;
 static decltype(&svbrdf_last_error) p_last_error;
 #define svbrdf_make_xrow p_make_xrow
 #define svbrdf_rendering_loss_workspace_bytes p_ws_bytes
@@ -37,6 +37,9 @@ int main()
     p_ws_bytes = (decltype(p_ws_bytes))dlsym(h, "svbrdf_rendering_loss_workspace_bytes");
     p_loss = (decltype(p_loss))dlsym(h, "svbrdf_mixed_loss_fwd_bwd_host_scenes");
     p_last_error = (decltype(p_last_error))dlsym(h, "svbrdf_last_error");
+    p_head = (decltype(p_head))dlsym(h, "svbrdf_head_loss_fwd_bwd_host_scenes");
+    const bool head = std::getenv("K3_HEAD") != nullptr;       // input = [B,9,H,W] encoded head output
+    if (head) p_loss = p_head;
     if (!p_make_xrow || !p_ws_bytes || !p_loss || !p_last_error) { std::printf("missing symbols in %s\n", libpath); return 1; }
     const std::string only = std::getenv("K3_MODES") ? std::getenv("K3_MODES") : "";
     const float l1w = std::getenv("K3_L1") ? (float)std::atof(std::getenv("K3_L1")) : 0.0f;
@@ -45,6 +48,7 @@ int main()
     const int steps = std::getenv("K3_STEPS") ? std::atoi(std::getenv("K3_STEPS")) : 1000;
     const size_t plane = (size_t)H * W, n = (size_t)B * 12 * plane;
     std::vector<float> in(n), tg(n), sc((size_t)B * S * 9), xr(W);
+    const int cin = head ? 9 : 12;
     for (int which = 0; which < 2; ++which) {
         std::vector<float> &m = which ? tg : in;
         for (int b = 0; b < B; ++b)
@@ -57,6 +61,11 @@ int main()
                 for (int k = 0; k < 3; ++k) { q[(3 + k) * plane] = urand(); q[(6 + k) * plane] = untied ? urand() : r; q[(9 + k) * plane] = urand(); }
             }
     }
+    if (head)       // encoded head output in [-1,1]: normals_xy | diffuse | roughness | specular, item stride 9 planes
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < 9; ++k)
+                for (size_t p = 0; p < plane; ++p)
+                    in[((size_t)b * 9 + k) * plane + p] = (k < 2 ? 0.25f : 0.9f) * (2.0f * urand() - 1.0f);
     for (size_t i = 0; i < sc.size() / 9; ++i) {
         float *q = &sc[i * 9];
         const float r1 = std::sqrt(0.001f + 0.899f * urand()), ph = 6.2831853f * urand(), d = 0.8f + 2.0f * urand();
@@ -82,9 +91,9 @@ int main()
     // part p of `parts` on stream s: items [p*B/parts, (p+1)*B/parts)
     auto launch = [&](int p, int parts, int s) -> int {
         const int b0 = p * B / parts, nb = (p + 1) * B / parts - b0;
-        return svbrdf_mixed_loss_fwd_bwd_host_scenes(d_in + (size_t)b0 * 12 * plane, d_tg + (size_t)b0 * 12 * plane,
+        return svbrdf_mixed_loss_fwd_bwd_host_scenes(d_in + (size_t)b0 * cin * plane, d_tg + (size_t)b0 * 12 * plane,
                                                      sc.data() + (size_t)b0 * S * 9, d_xr, 0.1f, l1w, 0.01f, d_loss + s,
-                                                     d_grad + (size_t)b0 * 12 * plane, (char *)d_ws + wsb * s, wsb, nb, S, H, W, st[s]);
+                                                     d_grad + (size_t)b0 * cin * plane, (char *)d_ws + wsb * s, wsb, nb, S, H, W, st[s]);
     };
     struct Mode { const char *name; int parts; bool join; bool alternate; };
     const Mode modes[] = {
