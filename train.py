@@ -63,6 +63,9 @@ def parse_args(argv=None):
     ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"))
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl on cuda, gloo on cpu)")
     ap.add_argument("--save", default=None, help="write a checkpoint (model + optimizer state) here at the end")
+    ap.add_argument("--resume", default=None,
+                    help="checkpoint to start from: one written by --save, or a checkpoint.tar of the reference "
+                         "(persistence.py:52-69; model weights only)")
     ap.add_argument("--autotune", action="store_true",
                     help="let MIOpen pick the fastest convolution algorithms (cudnn.benchmark) instead of the "
                          "reference's deterministic setting (utils.py:11-12)")
@@ -105,12 +108,17 @@ def run(args):
     if args.autotune:
         torch.backends.cudnn.deterministic = False
         torch.backends.cudnn.benchmark = True
+    if args.resume:
+        ck = torch.load(args.resume, map_location="cpu", weights_only=False)
+        net.load_state_dict(models.convert_reference_state_dict(ck["model_state_dict"]))
     net = net.to(dev).train()
     if args.channels_last:
         net = net.to(memory_format=torch.channels_last)
     model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank] if on_gpu else None) \
         if world > 1 else net
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
+    if args.resume and "optimizer_state_dict_amd" in ck:
+        optimizer.load_state_dict(ck["optimizer_state_dict_amd"])
 
     if args.loss == "l1":
         loss_fn = losses.SVBRDFL1Loss()
@@ -191,8 +199,13 @@ def run(args):
                          "data": args.data if args.data == "synthetic" else "tiled-png"}}
     if rank == 0:
         if args.save:
-            torch.save({"model_state_dict": net.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
-                        "model_type": args.model, "use_coords": not args.no_coords}, args.save)
+            # the reference's checkpoint.tar layout (persistence.py:52-69) with the REFERENCE's parameter names, so that
+            # its Checkpoint.restore_model_state loads the weights into its own SingleViewModel / MultiViewModel.  The
+            # optimizer state indexes parameters by position, which differs between the two module trees: it is kept
+            # under its own key instead of one the reference would load into the wrong slots.
+            torch.save({"model_type": args.model, "use_coords": not args.no_coords, "epoch": 0,
+                        "model_state_dict": models.convert_to_reference_state_dict(net.state_dict()),
+                        "optimizer_state_dict_amd": optimizer.state_dict(), "steps": total_steps}, args.save)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
