@@ -41,9 +41,9 @@
 // objects into libsvbrdf_hip.so:
 //   SVBRDF_TU=0  everything except the forward+adjoint loss kernels        (bottom-up post-RA scheduler)
 //   SVBRDF_TU=1  the forward+adjoint RenderingLoss kernels <GRAD, L1=0, HEAD=0> and their launcher
-//                                                                         (no post-RA scheduler, max-memory-clause)
 //   SVBRDF_TU=3  the forward+adjoint MixedLoss / head-fused kernels (L1 or HEAD set) and their launcher
-//                                                                         (no post-RA scheduler, iterative-minreg)
+//                (both: no post-RA scheduler, iterative-minreg strategy, round 1's register-assignment options;
+//                separate units so that each can take its own set again when the optimum moves)
 // SVBRDF_TU=2 (default; tools/ build the file with one command): everything in one unit.
 #ifndef SVBRDF_TU
 #define SVBRDF_TU 2
@@ -104,6 +104,9 @@ __device__ __forceinline__ float log2_(float x) { return SVBRDF_ABLATE == 8 ? x 
 #endif
 #ifndef SVBRDF_TIMING
 #define SVBRDF_TIMING 0            // 1: timing-only build, see tools/k3_cycles.py
+#endif
+#ifndef SVBRDF_K3_UNROLL2
+#define SVBRDF_K3_UNROLL2 1        // scene loop of the forward+adjoint kernels: two passes per trip, geometry ping-pong
 #endif
 #ifndef SVBRDF_K3_MIN_WAVES
 #define SVBRDF_K3_MIN_WAVES 4      // waves/SIMD the register allocator must leave room for (128 VGPRs)
@@ -342,26 +345,28 @@ template <int NL>
 __device__ __forceinline__ void shade_bwd(const VConst &K, const Geom &g, const MapK &m, const Dots &d, const Lobe lb[NL],
                                           const float F[3], const float f[3], const float g_rad[3], Grad &acc)
 {
-    float g_LNp = 0.0f, W[NL];
+    // (sums start from their first term, not from 0: `0 + x` is an instruction the compiler must keep -- it turns a
+    // -0 into +0 -- and this code is bound by the instruction count)
+    float g_LNp, W[NL];
     const float inv_pi = K.inv_pi;
-#pragma unroll
-    for (int l = 0; l < NL; ++l) W[l] = 0.0f;
+    const float omp = 1.0f - g.p;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const Lobe &l = lb[NL == 3 ? k : 0];
         const float gE = g_rad[k] * g.E[k];
         const float g_f = gE * d.LNp;
-        g_LNp = fma_(gE, f[k], g_LNp);
+        g_LNp = k == 0 ? gE * f[k] : fma_(gE, f[k], g_LNp);
         const float g_F = fma_(g_f, l.GD, -(g_f * m.dpi[k]));             // f = (1-F) d/pi + F GD
-        acc.s[k] = fma_(g_F, 1.0f - g.p, acc.s[k]);
+        acc.s[k] = fma_(g_F, omp, acc.s[k]);
         acc.d[k] = fma_(g_f * (1.0f - F[k]), inv_pi, acc.d[k]);
         const float gGD = g_f * F[k];                                     // d loss/d GD
         acc.r[k] = fma_(gGD * l.KA, m.r4m[k], acc.r[k]);
-        W[NL == 3 ? k : 0] += gGD;
+        if (NL == 3 || k == 0) W[NL == 3 ? k : 0] = gGD;
+        else W[0] += gGD;
     }
-    float g_VN = 0.0f, g_LN = 0.0f, sN = 0.0f;
+    float g_VN = W[0] * lb[0].KV, g_LN = W[0] * lb[0].KL, sN = W[0] * lb[0].KN;
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
+    for (int l = 1; l < NL; ++l) {
         g_VN = fma_(W[l], lb[l].KV, g_VN);
         g_LN = fma_(W[l], lb[l].KL, g_LN);
         sN = fma_(W[l], lb[l].KN, sN);
@@ -691,14 +696,24 @@ __device__ __forceinline__ void loss_pixel_scene(const VConst &K, const Geom &g,
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            float delta;
-            if (SVBRDF_ABLATE == 3) delta = b[k] - bt[k];
-            else if (SVBRDF_LOG_PER_TERM) delta = K.ln2 * (log2_(b[k]) - log2_(bt[k]));     // the reference's operation order
-            else delta = (b[k] == bt[k]) ? 0.0f : -K.ln2 * log2_(bt[k] * ib[k]);
-            lsum += fabsf(delta);
-            // d|delta|/d ri = sign(delta)/(N*ai), sign(0) = 0 as in torch
-            const float sg = __builtin_amdgcn_fmed3f(delta * K.huge, -1.0f, 1.0f);
-            g_rad[k] = sg * (nc * ib[k]);
+            if (SVBRDF_ABLATE == 3 || SVBRDF_LOG_PER_TERM) {
+                float delta;
+                if (SVBRDF_ABLATE == 3) delta = b[k] - bt[k];
+                else delta = K.ln2 * (log2_(b[k]) - log2_(bt[k]));     // the reference's operation order
+                lsum += fabsf(delta) * (1.0f / 0.693147180559945309417f);
+                const float sg = __builtin_amdgcn_fmed3f(delta * K.huge, -1.0f, 1.0f);
+                g_rad[k] = sg * (nc * ib[k]);
+                continue;
+            }
+            // lg = log2(at/ai) = -(log(ai) - log(at))/ln2.  The loss sums |lg| (scaled by ln2 ONCE, after the scene
+            // loop); d|delta|/d ri = sign(delta)/(N ai) = -sign(lg) nc/b: the magnitude nc*ib takes lg's sign bit with
+            // one v_and_or, and the minus rides as a source modifier on the product that consumes it.  sign(0) = 0 as in
+            // torch: equal operands select magnitude 0 (and lg = 0) explicitly.
+            const bool differ = b[k] != bt[k];
+            const float lg = differ ? log2_(bt[k] * ib[k]) : 0.0f;
+            lsum += fabsf(lg);
+            const float mag = differ ? nc * ib[k] : 0.0f;
+            g_rad[k] = -__builtin_bit_cast(float, __builtin_bit_cast(unsigned, mag) | (__builtin_bit_cast(unsigned, lg) & 0x80000000u));
         }
     }
     if (SVBRDF_ABLATE == 4) {
@@ -736,11 +751,12 @@ __device__ __forceinline__ void loss_pixel_scene_by_channel(const VConst &K, con
         const float ri = fi * (g.E[k] * di.LNp);
         const float b = fma_(ri, c, ec), bt = fma_(rt, c, ec);
         const float ib = rcp_(b);
-        const float delta = (b == bt) ? 0.0f : -K.ln2 * log2_(bt * ib);
-        lsum += fabsf(delta);
+        const bool differ = b != bt;
+        const float lg = differ ? log2_(bt * ib) : 0.0f;                // see loss_pixel_scene
+        lsum += fabsf(lg);
         if (WITH_GRAD) {
-            const float sg = __builtin_amdgcn_fmed3f(delta * K.huge, -1.0f, 1.0f);
-            const float g_rad = sg * (nc * ib);
+            const float mag = differ ? nc * ib : 0.0f;
+            const float g_rad = -__builtin_bit_cast(float, __builtin_bit_cast(unsigned, mag) | (__builtin_bit_cast(unsigned, lg) & 0x80000000u));
             const float gE = g_rad * g.E[k];
             const float g_f = gE * di.LNp;
             g_LNp = fma_(gE, fi, g_LNp);
@@ -808,21 +824,37 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt,
 #endif
     if (WITH_GRAD) {
         load_scene(scp, sc);
-        Geom g_next = geometry(K, sc, x, y);                     // render 0
+        Geom ga = geometry(K, sc, x, y), gb;                     // render 0
         load_scene(scp + (S > 1 ? 9 : 0), sc);                   // scalars of render 1
-        for (int s = 0; s < S; ++s) {
-            const Geom g = g_next;
-            asm volatile("" ::"s"(sc[0]), "s"(sc[8]));           // the wait for sc lands here, before the next loads
-            float cur[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) cur[i] = sc[i];
-            load_scene(scp + (s + 2 < S ? 18 : (s + 1 < S ? 9 : 0)), sc);
-            scp += (s + 1 < S) ? 9 : 0;
-            __builtin_amdgcn_sched_barrier(0);
-            // two independent streams from here to the end of the iteration:
-            g_next = geometry(K, cur, x, y);                     // render s+1 (a harmless repeat on the last pass)
-            loss_pixel_scene_any<NL, WITH_GRAD>(K, g, mi, mt, eps, inv_count, lsum, acc);
+        // One pass = shade render s with geometry G_CUR while the geometry of render s+1 goes into G_NEXT.  The loop
+        // body holds TWO passes with the roles of ga / gb swapped, so the pipelined geometry never has to be copied
+        // from a "next" to a "current" register set (9 v_mov per render in the rolled loop).
+#define SVBRDF_K3_PASS(G_CUR, G_NEXT)                                                                              \
+        {                                                                                                          \
+            asm volatile("" ::"s"(sc[0]), "s"(sc[8]));           /* the wait for sc lands here, before the next loads */ \
+            float cur[9];                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < 9; ++i) cur[i] = sc[i];                                          \
+            load_scene(scp + (s + 2 < S ? 18 : (s + 1 < S ? 9 : 0)), sc);                                           \
+            scp += (s + 1 < S) ? 9 : 0;                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            /* two independent streams from here to the end of the pass: */                                        \
+            G_NEXT = geometry(K, cur, x, y);                     /* render s+1 (a harmless repeat on the last pass) */ \
+            loss_pixel_scene_any<NL, WITH_GRAD>(K, G_CUR, mi, mt, eps, inv_count, lsum, acc);                      \
         }
+        if (SVBRDF_K3_UNROLL2) {
+            for (int s = 0;;) {
+                SVBRDF_K3_PASS(ga, gb)
+                if (++s >= S) break;
+                SVBRDF_K3_PASS(gb, ga)
+                if (++s >= S) break;
+            }
+        } else {
+            for (int s = 0; s < S; ++s) {
+                SVBRDF_K3_PASS(ga, gb)
+                ga = gb;
+            }
+        }
+#undef SVBRDF_K3_PASS
     } else {
         load_scene(sc_lds, sc);
         Geom g_next = geometry(K, sc, x, y);
@@ -833,6 +865,7 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt,
             loss_pixel_scene_any<NL, WITH_GRAD>(K, g, mi, mt, eps, inv_count, lsum, acc);
         }
     }
+    lsum *= 0.693147180559945309417f;       // the scene loop sums |log2|: natural log once per pixel
 #if SVBRDF_TIMING
     if (WITH_GRAD) {        // timing build: the normal-gradient planes carry loop cycles / 100 MHz ticks / start stamp
         acc.n[0] = (float)(clock64() - tm0);

@@ -25,14 +25,17 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 CSRC = os.path.join(ROOT, "svbrdf_estimation_amd", "csrc")
 HEADLINE = "k_rendering_loss_inlILb1ELb0ELb0"
 
-# budgets: measured values of the shipped build + a small margin (tools/isa_stats.py prints the current ones)
-TIED_LOOP_VALU_MAX = 342
-TIED_LOOP_TRANS = 13
-UNTIED_LOOP_VALU_MAX = 460           # RenderingLoss kernel: 451 (three lobes, channel by channel)
-UNTIED_LOOP_TRANS = 27
-UNTIED_EXTRA_VALU_MAX = {"mixed": 510, "head": 375}     # MixedLoss 498; head-fused 368 (input tied by construction)
-UNTIED_EXTRA_TRANS = {"mixed": 27, "head": 21}
-UNTIED_EXTRA_SCRATCH_MAX = {"mixed": 10, "head": 0}
+# budgets: measured values of the shipped build + a small margin (tools/isa_stats.py prints the current ones).
+# The scene loops hold TWO renders per trip (geometry ping-pong), so the counts are per two renders.
+RENDERS_PER_TRIP = 2
+TIED_LOOP_VALU_MAX = 650             # 640 = 320 per render (round 1: 336)
+TIED_LOOP_TRANS = 26                 # 13 per render
+UNTIED_LOOP_VALU_MAX = 880           # RenderingLoss kernel: 864 (three lobes, channel by channel)
+UNTIED_LOOP_TRANS = 54               # 27 per render
+UNTIED_EXTRA_VALU_MAX = {"mixed": 900, "head": 715}     # MixedLoss 884; head-fused 704 (input tied by construction)
+UNTIED_EXTRA_TRANS = {"mixed": 54, "head": 42}
+UNTIED_EXTRA_SCRATCH_MAX = {"mixed": 12, "head": 0}
+TIED_EXTRA_SCRATCH_MAX = {"mixed": 6, "head": 0}        # device-table MixedLoss kernel: 5 spill accesses per trip
 
 
 def _make_var(name):
@@ -85,7 +88,9 @@ def test_scene_loops_instruction_budget(adjoint_asm):
         print("untied loop: %s" % untied)
         assert tied["trans"] == TIED_LOOP_TRANS, tied
         assert tied["valu"] <= TIED_LOOP_VALU_MAX, tied
-        assert tied["scratch"] == 0 and tied["vmem"] == 0 and tied["lds"] == 0, tied
+        # (the device-table kernel fetches the next renders' scene rows inside the loop; the by-value kernel reads them
+        # with scalar loads from the kernel-argument segment)
+        assert tied["scratch"] == 0 and tied["vmem"] <= (0 if "_inl" in k else 8) and tied["lds"] == 0, tied
         assert tied["v_div"] == 0 and tied["v_pk"] == 0, tied
         assert untied["trans"] == UNTIED_LOOP_TRANS, untied
         assert untied["valu"] <= UNTIED_LOOP_VALU_MAX, untied
@@ -100,9 +105,10 @@ def test_mixed_and_head_fused_variants_budget(adjoint_extra_asm):
         _, meta, whole, loops, _, _ = isa_stats.analyse(adjoint_extra_asm, k)
         assert int(meta["NumVgprs"]) <= 128 and int(meta["Occupancy"]) >= 4, (k, meta)
         assert whole["v_div"] == 0 and whole["v_pk"] == 0, k
-        untied, tied = sorted(loops, key=lambda c: -c["valu"])
         kind = "head" if k.endswith("Lb1EEEvNS_10SceneBlockEPKfS3_S3_ffdfNS_8L1ParamsEPfPyS5_iii") or "ELb1EEEvPKf" in k else "mixed"
-        assert tied["scratch"] == 0 and tied["trans"] == TIED_LOOP_TRANS and tied["valu"] <= TIED_LOOP_VALU_MAX, (k, tied)
+        tied = min((c for c in loops if c["trans"] == TIED_LOOP_TRANS), key=lambda c: c["valu"])
+        untied = max(loops, key=lambda c: c["valu"])
+        assert tied["scratch"] <= TIED_EXTRA_SCRATCH_MAX[kind] and tied["valu"] <= TIED_LOOP_VALU_MAX, (k, tied)
         assert untied["trans"] == UNTIED_EXTRA_TRANS[kind] and untied["valu"] <= UNTIED_EXTRA_VALU_MAX[kind], (k, kind, untied)
         assert untied["scratch"] <= UNTIED_EXTRA_SCRATCH_MAX[kind], (k, kind, untied)
 

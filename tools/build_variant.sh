@@ -9,8 +9,8 @@ out=../../tools/_build
 mkdir -p $out/obj_$tag
 F="-O3 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -std=c++17 -fvisibility=hidden -I../../include $*"
 SM=${SCHED_MAIN:--mllvm -misched-postra-direction=bottomup}
-SA=${SCHED_ADJOINT:--mllvm -enable-post-misched=0 -mllvm -amdgpu-sched-strategy=max-memory-clause}
-SX=${SCHED_ADJOINT_EXTRA:--mllvm -enable-post-misched=0 -mllvm -amdgpu-sched-strategy=iterative-minreg}
+SA=${SCHED_ADJOINT:--mllvm -enable-post-misched=0 -mllvm -amdgpu-sched-strategy=iterative-minreg -mllvm -greedy-regclass-priority-trumps-globalness=1 -mllvm -greedy-reverse-local-assignment}
+SX=${SCHED_ADJOINT_EXTRA:-$SA}
 /opt/rocm/bin/hipcc $F $SM -DSVBRDF_TU=0 -c -o $out/obj_$tag/main.o svbrdf_kernels.hip &
 /opt/rocm/bin/hipcc $F $SA -DSVBRDF_TU=1 -c -o $out/obj_$tag/adj.o svbrdf_kernels.hip &
 /opt/rocm/bin/hipcc $F $SX -DSVBRDF_TU=3 -c -o $out/obj_$tag/adjx.o svbrdf_kernels.hip &
