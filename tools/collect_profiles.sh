@@ -3,14 +3,19 @@
 # Usage: gpurun -- 'bash tools/collect_profiles.sh r01'
 # Outputs land in gpurun_out/<tag>_*; tools/summarize_profiles.py turns them into profiles/<tag>_*.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --no-cpu-baseline --no-secondary"
-# kernel-trace + stats (no counters in this pass)
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats --output-format csv -- $BENCH --steps 200 --warmup 20 > $OUT/${TAG}_stats.log 2>&1
+# kernel-trace + stats (no counters in these passes): the default command (steps on two streams: launches overlap, so the
+# per-launch duration exceeds a launch's share of the GPU) and the same with every step on one stream (the duration of a
+# launch on its own: what bench.py reports as roofline.one_launch_alone / single_stream)
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats --output-format csv -- $BENCH --steps 400 --warmup 50 > $OUT/${TAG}_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats1 --output-format csv -- $BENCH --steps 400 --warmup 50 --streams 1 > $OUT/${TAG}_stats1.log 2>&1
+# the counter passes run one launch at a time (--streams 1) over the six rotating batches (302 MB: beyond the Infinity Cache)
+BENCH="$BENCH --streams 1"
 # HBM traffic: FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots)
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch --output-format csv -- $BENCH --steps 20 --warmup 5 > $OUT/${TAG}_pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write --output-format csv -- $BENCH --steps 20 --warmup 5 > $OUT/${TAG}_pmc_write.log 2>&1

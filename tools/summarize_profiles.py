@@ -13,7 +13,7 @@ algorithmic reads; WRITE_SIZE is exact.
 import collections, csv, glob, json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 
@@ -25,7 +25,10 @@ def one(pattern):
 
 st = one("%s_stats/*/*_kernel_stats.csv" % tag)
 if st:
-    shutil.copy(st, os.path.join(P, "%s_kernel_stats.csv" % tag))
+    shutil.copy(st, os.path.join(P, "%s_kernel_stats.csv" % tag))                 # default command: two streams
+st1 = one("%s_stats1/*/*_kernel_stats.csv" % tag)
+if st1:
+    shutil.copy(st1, os.path.join(P, "%s_kernel_stats_streams1.csv" % tag))      # --streams 1: one launch at a time
 summary = {}
 for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     f = one("%s_%s/*/*_counter_collection.csv" % (tag, p))
@@ -53,7 +56,9 @@ if k3 and "FETCH_SIZE" in summary[k3] and "WRITE_SIZE" in summary[k3]:
                "read_bytes_corrected": 2.0 * fetch_kib * 1024.0, "write_bytes": write_kib * 1024.0,
                "hbm_bytes_per_launch": 2.0 * fetch_kib * 1024.0 + write_kib * 1024.0,
                "correction": "gfx950: FETCH_SIZE x2 for coalesced streaming reads (MI355X_MICROARCH.md, HBM)",
-               "B": cfg.get("global_batch"), "H": cfg.get("H"), "S": cfg.get("scenes"), "round": tag}
+               "B": cfg.get("global_batch"), "H": cfg.get("H"), "S": cfg.get("scenes"), "round": tag,
+               "distinct_batches": cfg.get("distinct_batches"), "working_set_MiB": cfg.get("working_set_MiB"),
+               "git_head": os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip() or "?"}
     for key, counter in (("valu_wave_instr_per_launch", "SQ_INSTS_VALU"), ("trans_wave_instr_per_launch", "SQ_INSTS_VALU_TRANS_F32")):
         if counter in summary[k3]:
             traffic[key] = summary[k3][counter]["mean"]
