@@ -64,6 +64,26 @@ class _FusedRenderingLoss(torch.autograd.Function):
         return grad_in, grad_tg, None, None, None, None, None
 
 
+class _FusedLossTensor(torch.Tensor):
+    """The 0-dim loss the native host path returns for a LEAF input (a material being optimised directly, the bench
+    loop): an ordinary tensor, attached to the autograd graph as usual, whose ``backward()`` first asks the extension
+    whether the call is exactly "accumulate the gradient the kernel already produced into ``input.grad``" (plain
+    ``loss.backward()``: no explicit gradient, no retain/create graph, no ``inputs=``; leaf without hooks; same
+    stream) and, if so, does just that instead of a trip through the autograd engine (a fill kernel for the implicit
+    ones tensor, a graph task, a no-op scale launch: 19 -> 3 us of host time).  Every other use -- including a
+    second ``backward()``, arithmetic on the loss, ``torch.autograd.grad`` -- goes through autograd unchanged."""
+
+    __torch_function__ = torch._C._disabled_torch_function_impl      # ops on it return plain tensors, no dispatch cost
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        src = self.__dict__.pop("_svbrdf_src", None)
+        if src is not None and gradient is None and not retain_graph and not create_graph and inputs is None:
+            inner, leaf, ext = src
+            if ext.fast_backward(inner, leaf, _native._raw_stream(leaf.device)):
+                return None
+        return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs)
+
+
 def _check_shapes(input, target):
     if input.dim() != 4 or input.shape != target.shape or input.shape[1] != 12:
         raise ValueError("input and target must both be [B,12,H,W]")
@@ -104,9 +124,14 @@ class RenderingLoss(nn.Module):
         if ext is not None and input.dtype == torch.float32 and target.dtype == torch.float32 \
                 and input.device.index == torch.cuda.current_device():
             # native host path: same draws, same kernels, no interpreter in the loop
-            return ext.fused_loss(input, target, int(self.random_configuration_count),
+            loss = ext.fused_loss(input, target, int(self.random_configuration_count),
                                   int(self.specular_configuration_count), float(self.epsilon_render),
                                   float(l1_weight), float(eps_l1), _native._raw_stream(input.device), bool(head))
+            if input.is_leaf and input.requires_grad and not target.requires_grad and torch.is_grad_enabled():
+                out = loss.as_subclass(_FusedLossTensor)       # see _FusedLossTensor: backward() may skip the engine
+                out.__dict__["_svbrdf_src"] = (loss, input, ext)
+                return out
+            return loss
         table = self.sample_scene_table(input.shape[0])
         if not input.is_cuda:
             raise _native.NativeLibraryError(

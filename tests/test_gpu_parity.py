@@ -920,6 +920,72 @@ def test_unet_forward_equals_reference_fixture_on_the_gpu(dev, golden, tag):
     print("U-Net %s on the GPU vs reference fixture: max abs err %.2e" % (tag, err))
 
 
+def test_leaf_backward_shortcut_equals_the_autograd_engine(dev, golden):
+    """`loss.backward()` on a leaf input resolves, in the native host path, to "input.grad (+)= the buffer the kernel
+    wrote" without a trip through the autograd engine.  It must be indistinguishable from the engine: same bits, same
+    accumulation into an existing .grad, and every case it does not cover (hooks, explicit gradient, arithmetic on
+    the loss, another stream, a target that needs a gradient, a second backward) must still go through autograd."""
+    from svbrdf_estimation_amd import _hostext, losses, renderers
+    assert _hostext.module() is not None
+    g = golden("g3_loss_48.npz")
+    d_in, d_tg = _t(g["input"], dev), _t(g["target"], dev)
+    fn = losses.MixedLoss(renderers.LocalRenderer())
+
+    def run(how, x=None, tg=d_tg):
+        x = d_in.clone().requires_grad_(True) if x is None else x
+        torch.manual_seed(5)
+        loss = fn(x, tg)
+        how(loss, x)
+        torch.cuda.synchronize()
+        return loss, x
+
+    engine = run(lambda l, x: torch.Tensor.backward(l))                  # the plain autograd engine
+    fast = run(lambda l, x: l.backward())
+    assert isinstance(fast[0], losses._FusedLossTensor) and "_svbrdf_src" not in fast[0].__dict__    # shortcut taken
+    assert fast[0].item() == engine[0].item() and torch.equal(fast[1].grad, engine[1].grad)
+    with pytest.raises(RuntimeError):
+        fast[0].backward()                                               # already back-propagated: the engine says so
+    # accumulation into an existing gradient
+    x = d_in.clone().requires_grad_(True)
+    x.grad = torch.ones_like(x)
+    acc = run(lambda l, x: l.backward(), x=x)
+    assert torch.equal(acc[1].grad, engine[1].grad + 1.0)
+    # a tensor hook must run (engine path) and see the gradient
+    seen = []
+    x = d_in.clone().requires_grad_(True)
+    x.register_hook(lambda gr: seen.append(gr.clone()))
+    hooked = run(lambda l, x: l.backward(), x=x)
+    assert len(seen) == 1 and torch.equal(seen[0], engine[1].grad) and torch.equal(hooked[1].grad, engine[1].grad)
+    # explicit upstream gradient, arithmetic on the loss, torch.autograd.grad
+    scaled = run(lambda l, x: l.backward(torch.tensor(2.0, device=dev)))
+    assert torch.allclose(scaled[1].grad, engine[1].grad * 2.0, rtol=0, atol=0)
+    arith = run(lambda l, x: (l * 3.0).backward())
+    assert torch.equal(arith[1].grad, engine[1].grad * 3.0)
+    x = d_in.clone().requires_grad_(True)
+    torch.manual_seed(5)
+    (ga,) = torch.autograd.grad(fn(x, d_tg), x)
+    assert torch.equal(ga, engine[1].grad) and x.grad is None
+    # backward issued from another stream than the forward: the engine path (with its stream sync) is taken
+    side = torch.cuda.Stream(dev)
+    def other_stream(l, x):
+        with torch.cuda.stream(side):
+            l.backward()
+    moved = run(other_stream)
+    assert torch.equal(moved[1].grad, engine[1].grad)
+    # a target that needs its gradient too
+    tg = d_tg.clone().requires_grad_(True)
+    both = run(lambda l, x: l.backward(), tg=tg)
+    assert not isinstance(both[0], losses._FusedLossTensor)
+    assert torch.equal(both[1].grad, engine[1].grad) and tg.grad is not None and bool(tg.grad.abs().sum() > 0)
+    # a non-leaf input (the training case: the maps come out of a network) never takes the shortcut
+    w = torch.ones(1, device=dev, requires_grad=True)
+    torch.manual_seed(5)
+    loss = fn(d_in * w, d_tg)
+    assert not isinstance(loss, losses._FusedLossTensor)
+    loss.backward()
+    assert torch.isfinite(w.grad).all()
+
+
 # ---------------------------------------------------------------- streams
 
 def test_non_default_and_concurrent_streams(dev, native, golden):
