@@ -462,6 +462,73 @@ __device__ __forceinline__ void store_grads(float *__restrict__ base, size_t pla
     }
 }
 
+// K3's 36 plane accesses (one pixel per lane): the plane base is wave-uniform (kernel argument + batch item + channel),
+// the lane contributes a 32-bit pixel index.  Buffer instructions express exactly that: one 128-bit resource per tensor
+// and batch item in SGPRs (base, byte size), the lane's byte offset in ONE VGPR computed once, the plane's byte offset
+// as the scalar offset operand -- all address arithmetic on the scalar unit.  With flat 64-bit addresses the compiler
+// spends ~100 VALU instructions per pixel on v_mad_u64_u32 / v_lshl_add_u64 pairs, in a kernel that is bound by VALU
+// issue.  One item's planes must stay below 2 GiB (checked on the host: H*W <= 2^25).
+#ifndef SVBRDF_K3_ADDR32
+#define SVBRDF_K3_ADDR32 1
+#endif
+struct PlaneBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned lane_bytes;        // pixel index * 4
+    unsigned plane_bytes;       // H*W*4
+};
+__device__ __forceinline__ PlaneBuf plane_buf(const float *item_base, int planes, size_t plane, size_t pix)
+{
+    PlaneBuf p;
+    p.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(item_base), 0, (int)(planes * plane * sizeof(float)),
+                                               0x00020000);     // gfx9 raw dword buffer
+    p.lane_bytes = (unsigned)pix * 4u;
+    p.plane_bytes = (unsigned)plane * 4u;
+    return p;
+}
+__device__ __forceinline__ float plane_load(const PlaneBuf &p, int k)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(p.rsrc, p.lane_bytes, k * p.plane_bytes, 0));
+}
+__device__ __forceinline__ void plane_store(const PlaneBuf &p, int k, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), p.rsrc, p.lane_bytes, k * p.plane_bytes, 0);
+}
+
+__device__ __forceinline__ void load_maps_k3(const float *__restrict__ base, size_t plane, size_t pix, Maps &m)
+{
+    if (!SVBRDF_K3_ADDR32) {
+        Maps t[1];
+        load_maps<1>(base, plane, pix, t);
+        m = t[0];
+        return;
+    }
+    const PlaneBuf p = plane_buf(base, 12, plane, pix);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        m.n[k] = plane_load(p, 0 + k);
+        m.d[k] = plane_load(p, 3 + k);
+        m.r[k] = plane_load(p, 6 + k);
+        m.s[k] = plane_load(p, 9 + k);
+    }
+}
+
+__device__ __forceinline__ void store_grads_k3(float *__restrict__ base, size_t plane, size_t pix, const Grad &g)
+{
+    if (!SVBRDF_K3_ADDR32) {
+        const Grad t[1] = {g};
+        store_grads<1>(base, plane, pix, t);
+        return;
+    }
+    const PlaneBuf p = plane_buf(base, 12, plane, pix);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        plane_store(p, 0 + k, g.n[k]);
+        plane_store(p, 3 + k, g.d[k]);
+        plane_store(p, 6 + k, g.r[k]);
+        plane_store(p, 9 + k, g.s[k]);
+    }
+}
+
 __device__ __forceinline__ void zero_grad(Grad &g)
 {
 #pragma unroll
@@ -969,16 +1036,22 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         Head head;
         if (HEAD) {     // input is the [B,9,H,W] post-tanh generator output
             float e[9];
-            const float *__restrict__ ip = input + (size_t)b * 9 * plane + pix;
+            const float *__restrict__ ip = input + (size_t)b * 9 * plane;
+            if (SVBRDF_K3_ADDR32) {
+                const PlaneBuf pb = plane_buf(ip, 9, plane, pix);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) e[k] = ip[(size_t)k * plane];
+                for (int k = 0; k < 9; ++k) e[k] = plane_load(pb, k);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) e[k] = ip[(size_t)k * plane + pix];
+            }
             head = decode_head(e, in[0]);
         } else {
             if (SVBRDF_ABLATE == 6) fake_maps(pix, 0.0f, in[0]);
-            else load_maps<1>(input + (size_t)b * 12 * plane, plane, pix, in);
+            else load_maps_k3(input + (size_t)b * 12 * plane, plane, pix, in[0]);
         }
         if (SVBRDF_ABLATE == 6) fake_maps(pix, 0.05f, tg[0]);
-        else load_maps<1>(target + (size_t)b * 12 * plane, plane, pix, tg);
+        else load_maps_k3(target + (size_t)b * 12 * plane, plane, pix, tg[0]);
         Grad acc;
         zero_grad(acc);
         float l1sum = 0.0f;
@@ -1052,13 +1125,18 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
             if (HEAD) {
                 float ge[9];
                 head_bwd(head, acc, ge);
-                float *__restrict__ gp = grad_input + (size_t)b * 9 * plane + pix;
+                float *__restrict__ gp = grad_input + (size_t)b * 9 * plane;
+                if (SVBRDF_K3_ADDR32) {
+                    const PlaneBuf pb = plane_buf(gp, 9, plane, pix);
 #pragma unroll
-                for (int k = 0; k < 9; ++k) gp[(size_t)k * plane] = ge[k];
+                    for (int k = 0; k < 9; ++k) plane_store(pb, k, ge[k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) gp[(size_t)k * plane + pix] = ge[k];
+                }
             } else {
-                const Grad out[1] = {acc};
                 if (SVBRDF_ABLATE != 7 || lsum == -12345.0f)
-                    store_grads<1>(grad_input + (size_t)b * 12 * plane, plane, pix, out);
+                    store_grads_k3(grad_input + (size_t)b * 12 * plane, plane, pix, acc);
             }
         }
     }
@@ -1503,6 +1581,8 @@ static int loss_impl(const char *who, bool head, bool scenes_on_host, const floa
         return fail(SVBRDF_ERR_WORKSPACE, "loss: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long long plane = (long long)H * W;
+    if (plane > (1LL << 25))
+        return fail(SVBRDF_ERR_DIMS, "loss: H*W exceeds 2^25 (one item's 12 planes are addressed with 32-bit byte offsets)");
     const dim3 grid((unsigned)((plane + kLossThreads - 1) / kLossThreads), (unsigned)B, 1), block(kLossThreads);
     const double count = (double)B * S * 3.0 * (double)plane;
     const float inv_count = (float)(1.0 / count);
