@@ -255,8 +255,8 @@ def secondary_kernels(dev, H):
                     "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBPS}
     from svbrdf_estimation_amd import losses, renderers
     mixed = losses.MixedLoss(renderers.LocalRenderer())
-    # BASELINE configs[3]: batch 16, mixed loss (the multi-view network's output has the same loss shapes); 144 scene
-    # rows exceed the kernel-argument route, so the table is uploaded (pinned ring)
+    # BASELINE configs[3]: batch 16, mixed loss (the multi-view network's output has the same loss shapes); its 144 scene
+    # rows ride in the launch's argument block like config 2's 72
     k3_module("K3_config4_B16_mixed_loss", 16, H, mixed, 1)
     k3_module("K3_config4_B16_mixed_loss_2streams", 16, H, mixed, 2)
     k3("K3_config2_roughness_U(0.2,1)", 8, H, 3, 6, rough_min=0.2)

@@ -142,11 +142,12 @@ SVBRDF_API int svbrdf_head_loss_fwd_bwd(const float *encoded9, const float *targ
  * kernel-argument block of the launch (consumed before the call returns: `scenes_host` may be
  * reused or freed immediately), so the call enqueues ONE kernel dispatch and nothing else -- no
  * device buffer for the table, no H2D copy command, no pinned staging.  Limit:
- * B*S <= SVBRDF_HOST_SCENES_MAX_ROWS (the argument block is 4 KB); larger tables return
+ * B*S <= SVBRDF_HOST_SCENES_MAX_ROWS (288 rows = a 10 KB argument block: configs[3]'s 16 x 9 and config 5's
+ * 8 x 32 rows fit; the HIP runtime on gfx950 takes argument blocks of at least 32 KB, measured); larger tables return
  * SVBRDF_ERR_DIMS and go through the device-pointer entry points above.  Everything else
  * (results, scratch, stream semantics) is identical to svbrdf_mixed_loss_fwd_bwd /
  * svbrdf_head_loss_fwd_bwd; l1_weight = 0 gives the plain RenderingLoss. */
-#define SVBRDF_HOST_SCENES_MAX_ROWS 96
+#define SVBRDF_HOST_SCENES_MAX_ROWS 288
 SVBRDF_API int svbrdf_host_scenes_max_rows(void);
 SVBRDF_API int svbrdf_mixed_loss_fwd_bwd_host_scenes(const float *input, const float *target,
                                                      const float *scenes_host, const float *xrow,

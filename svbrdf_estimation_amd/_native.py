@@ -365,7 +365,7 @@ def clock_probe(out, ticks=300000, stream=None):
 
 
 def host_scenes_max_rows():
-    """largest B*S the *_host_scenes entry points take (the table rides in the 4 KB kernel-argument block)"""
+    """largest B*S the *_host_scenes entry points take (the table rides in the launch's kernel-argument block)"""
     return int(_load().svbrdf_host_scenes_max_rows())
 
 

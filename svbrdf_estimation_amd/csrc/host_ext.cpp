@@ -4,7 +4,7 @@
 // 160-220 us per call on the GPU box, 3x the fused kernel it launches.  This extension does the
 // same three things -- draw the scenes (reference RNG order, development/multiImage_pytorch/
 // losses.py:35 -> environment.py:18-55 -> utils.py:100-111), hand the [B,S,9] table to the kernel
-// (by value with the launch when it has <= 96 rows, through a pinned upload ring otherwise), launch
+// (by value with the launch when it has <= 288 rows, through a pinned upload ring otherwise), launch
 // svbrdf_{mixed,head}_loss_fwd_bwd[_host_scenes] and hang the precomputed gradient on a C++
 // autograd node -- without the Python interpreter in the loop.  It contains no arithmetic of
 // the hot path: the kernels live in libsvbrdf_hip.so and are reached through the C ABI
@@ -411,7 +411,7 @@ at::Tensor fused_loss(const at::Tensor &input, const at::Tensor &target, int64_t
     const int64_t S = n_random + n_specular;
     ensure_device_state(input, (int)S, stream);
     if (B * S <= g_abi.host_rows) {
-        // small table (every reference configuration with B*S <= 96): drawn into a host buffer and handed to the
+        // small table (B*S <= 288: every BASELINE configuration at its per-GPU batch): drawn into a host buffer and handed to the
         // launch by value -- the step is ONE dispatch, no H2D command, no device buffer, no pinned slot
         if (!g_state.host_table.defined() || g_state.host_table.size(0) != B || g_state.host_table.size(1) != S)
             g_state.host_table = at::empty({B, S, 9}, at::TensorOptions().dtype(at::kFloat));

@@ -1212,13 +1212,16 @@ __global__ SVBRDF_K3_ATTRS void k_rendering_loss(const float *__restrict__ input
 // ~24 us of host time per call and makes the step host-bound at ~60 us; this route leaves one
 // dispatch per step and the loop GPU-bound at the kernel's own ~53 us.  The body reads the rows
 // with the same wave-uniform scalar loads, from the kernarg segment instead of a global buffer.
+// Capacity: 288 rows (10,368 bytes) -- configs[3] (16 x 9 rows) and config 5 at batch 8 (8 x 32) fit; the
+// runtime takes argument blocks of 32 KB and more on gfx950 (tools: a by-value struct of 32,000 bytes launches and
+// reads back correctly), and marshalling 10 KB costs the launch ~0.2 us.
 struct SceneBlock {
     float v[SVBRDF_HOST_SCENES_MAX_ROWS * 9];
 };
 
 // `table` is the FIRST argument, i.e. it sits at offset 0 of the kernarg segment, and is read through
 // the segment pointer: taking the address of the by-value parameter itself makes the compiler
-// copy all 3456 bytes into scratch in the adjoint variants (seen in the resource report).
+// copy the whole block into scratch in the adjoint variants (seen in the resource report).
 template <bool WITH_GRAD, bool WITH_L1, bool HEAD>
 __global__ SVBRDF_K3_ATTRS void k_rendering_loss_inl([[maybe_unused]] const SceneBlock table,
                                                      const float *__restrict__ input, const float *__restrict__ target,
