@@ -1102,7 +1102,15 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         const bool tied = tied_roughness(in[0]) && tied_roughness(tg[0]);
         const MapK mi = prepare<WITH_GRAD>(in[0]), mt = prepare<false>(tg[0]);
         float x[1], y;
-        pixel_coords<1>(xrow, pix, W, x, y);
+        if ((W & (W - 1)) == 0) {
+            // power-of-two width (256, 512: every BASELINE configuration): row and column by shift and mask instead of a
+            // 64-bit division (~25 VALU instructions, several of them quarter-rate integer multiplies)
+            const unsigned p32 = (unsigned)pix, sh = (unsigned)__builtin_ctz((unsigned)W);
+            x[0] = xrow[p32 & (unsigned)(W - 1)];
+            y = -xrow[p32 >> sh];
+        } else {
+            pixel_coords<1>(xrow, pix, W, x, y);
+        }
         {
             // torch.clamp propagates NaN (renderers.py:48-52, 87), v_max_f32 returns the other operand: a NaN (or
             // infinite) normal or roughness value would vanish in the clamps and leave a finite loss beside NaN
