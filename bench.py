@@ -348,9 +348,9 @@ def main():
 
     # HIP events around the kernel launch on the launch stream, on every `stride`-th timed step (a timing
     # event is an end-of-pipe timestamp: bracketing EVERY launch costs ~10 us of GPU idle per step once the
-    # loop is GPU-bound, so the launches are sampled instead: every 16th at the default 2000 steps = 125 samples,
+    # loop is GPU-bound, so the launches are sampled instead: every 32nd at the default 2000 steps = 63 samples,
     # and at least 2 samples however few steps are asked for)
-    stride = max(1, min(16, args.steps // 2))
+    stride = max(1, min(32, args.steps // 2))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           if i % stride == 0 else None for i in range(args.steps)]
     state = {"i": -1}
