@@ -563,6 +563,7 @@ def main():
                          "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
                          "kernel_ms_note": "event-bracketed duration of a launch in the timed region (with N > 1 streams it "
                                            "overlaps its neighbours and exceeds time_per_launch_ms)",
+                         "launches_in_flight": n_streams,
                          "kernel_launches_timed": len(kernel_ms),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "valu_frac_of_fp32_peak": (FLOP_PER_PIXEL_SCENE * H * H * S * B / (share_ms * 1e-3))
