@@ -76,6 +76,32 @@ def test_headline_kernel_resources(adjoint_asm):
     print("headline kernel: %s" % {k: meta[k] for k in ("NumVgprs", "TotalNumSgprs", "ScratchSize", "Occupancy")})
 
 
+def test_plane_loads_are_issued_back_to_back(adjoint_asm, adjoint_extra_asm):
+    """The 24 plane loads of a pixel (18-21 with the head fused) must be in flight together: the iterative-minreg
+    scheduler likes to sink a load to its first use, and a prologue in which every load is followed by
+    `s_waitcnt vmcnt(0)` (seen when the coordinate loads were moved in front of them) serialises 24 memory latencies
+    in front of every wave's scene loop.  Checked: between the first and the last plane load of each forward+adjoint
+    kernel there is no vector-memory wait at all."""
+    import isa_stats
+    for text in (adjoint_asm, adjoint_extra_asm):
+        for k in isa_stats.kernels(text):
+            if "k_rendering_loss" not in k:
+                continue
+            _, _, _, _, ins, rng = isa_stats.analyse(text, k)
+            first_loop = min(a for a, _ in rng)
+            loads = [i for i, (_, _, mn, ops) in enumerate(ins[:first_loop])
+                     if mn and mn.startswith("buffer_load_dword")]
+            assert len(loads) >= 18, (k, len(loads))
+            # head-fused kernels decode the 9 encoded planes before they load the target: two groups there
+            groups, start = [], loads[0]
+            for a, b in zip(loads, loads[1:]):
+                if any(m == "s_waitcnt" and "vmcnt" in o for _, _, m, o in ins[a:b] if m):
+                    groups.append((start, a))
+                    start = b
+            groups.append((start, loads[-1]))
+            assert len(groups) <= 2, "%s: plane loads split into %d groups by s_waitcnt vmcnt" % (k, len(groups))
+
+
 def test_scene_loops_instruction_budget(adjoint_asm):
     import isa_stats
     names = [k for k in isa_stats.kernels(adjoint_asm) if "k_rendering_loss" in k]
