@@ -410,10 +410,10 @@ def main():
         last = step()
     state["i"] = -1
     torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0      # this rank's K steps are done; the job's time is the MAX over ranks (below)
     if dist is not None:
-        barrier()
+        barrier()                           # closing bracket: every rank has finished before anything else happens
     torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
     if ns:
         torch.cuda.set_stream(torch.cuda.default_stream(dev))
     _native.set_launch_hook(None)
