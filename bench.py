@@ -56,10 +56,17 @@ def parse_args():
                          "multi-rank control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-device", action="store_true",
                     help="every rank uses cuda:0 (plumbing tests only, with --backend gloo)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: still create the process group (world size 1) and take every multi-rank branch -- "
+                         "RCCL init with device_id, barrier(device_ids=...), the MAX all-reduce of the elapsed time on a "
+                         "device tensor, the global-mean all-reduce -- so that the code an N-GPU run executes can be "
+                         "exercised on a one-GPU box (tests/test_gpu_multirank.py)")
+    ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the steps are issued on, round-robin (step k runs entirely -- forward launch and "
-                         "backward -- on stream k mod N).  Steps are independent batches, so with N = 2 the ramp and tail "
-                         "of one step's kernel are filled by the next step's (DESIGN.md section 5)")
+                         "backward -- on stream k mod N).  Default 1: what a training loop, whose steps are serialised by the "
+                         "optimizer, gets -- this is `value`.  Steps of a bench loop are independent batches, so with N = 2 "
+                         "the ramp and tail of one step's kernel are filled by the next step's; that figure is reported "
+                         "beside the headline as `two_streams_overlapped` (DESIGN.md section 5.1)")
     ap.add_argument("--rotate", type=int, default=6,
                     help="distinct (input, target) batches visited round-robin by the steps; 6 x 50 MB exceeds the "
                          "256 MiB Infinity Cache")
@@ -253,7 +260,75 @@ def secondary_kernels(dev, H):
         gb = 144.0 * Hk * Hk * B / (ms * 1e-3) / 1e9
         out[tag] = {"B": B, "H": Hk, "streams": n_streams, "ms_per_step": ms, "patches_per_s": B / (ms * 1e-3),
                     "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBPS}
-    from svbrdf_estimation_amd import losses, renderers
+    from svbrdf_estimation_amd import losses, renderers, synthesis
+
+    # SURVEY 8d's secondary metric: renders/s THROUGH the plugin interface, `LocalRenderer().render(scene, svbrdf)`
+    # (renderers.py:67-104), one reference-shaped call after the other: a Scene object of python lists, one [12,H,W]
+    # map (-> [1,3,H,W]) or a [8,12,H,W] batch with the one scene; forward, and forward + backward of a cotangent.
+    # The call is one dispatch (the scene's nine floats ride in the launch's argument block), so with a 256x256 map it is
+    # host-bound: us_per_call is host time.
+    R = renderers.LocalRenderer()
+    scene = environment.Scene(environment.Camera([0.1, -0.2, 2.0]), environment.Light([0.4, 0.3, 1.5], [30.0, 30.0, 30.0]))
+    gen = torch.Generator().manual_seed(17)
+    for tag, nb in (("LocalRenderer_render_one_map", 0), ("LocalRenderer_render_batch8", 8)):
+        m = synthetic_maps(gen, max(nb, 1), H).to(dev)
+        m = m if nb else m[0]
+        cot = torch.randn(max(nb, 1), 3, H, H, device=dev)
+        x = m.clone().requires_grad_(True)
+        res = {}
+        for mode in ("fwd", "fwd_bwd"):
+            def call():
+                if mode == "fwd":
+                    R.render(scene, m)
+                else:
+                    x.grad = None
+                    R.render(scene, x).backward(cot)
+            for _ in range(50):
+                call()
+            torch.cuda.synchronize(dev)
+            n = 500
+            t0 = time.perf_counter()
+            for _ in range(n):
+                call()
+            host_s = time.perf_counter() - t0        # the host's share: every call issued, the GPU still working
+            torch.cuda.synchronize(dev)
+            wall = time.perf_counter() - t0
+            res[mode] = {"renders_per_s": n * max(nb, 1) / wall, "us_per_call": 1e6 * wall / n,
+                         "host_us_per_call": 1e6 * host_s / n}
+        res["maps_per_call"] = max(nb, 1)
+        out[tag] = res
+    # K4 (material mixing, dataset.py:142-160) and the input-photo synthesis on K1 (dataset.py:162-221), per call
+    Bm = 64
+    a, b = synthetic_maps(gen, Bm, H).to(dev), synthetic_maps(gen, Bm, H).to(dev)
+    alpha = torch.rand(Bm, device=dev) * 0.8 + 0.1
+    for _ in range(3):
+        _native.mix_materials(a, b, alpha)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        _native.mix_materials(a, b, alpha)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / 20
+    gb = 144.0 * H * H * Bm / (ms * 1e-3) / 1e9
+    out["K4_mix_materials"] = {"samples_per_launch": Bm, "ms_per_launch": ms, "algorithmic_GBps": gb,
+                               "frac_of_hbm_peak": gb / HBM_PEAK_GBPS, "samples_per_s": Bm / (ms * 1e-3),
+                               "working_set_MiB": 36.0 * H * H * 4 * Bm / 2 ** 20}
+    for views, Bs in ((1, 8), (5, 16)):
+        sv = a[:Bs]
+        for _ in range(3):
+            synthesis.render_inputs(sv, views)
+        torch.cuda.synchronize(dev)
+        t0, n = time.perf_counter(), 30
+        for _ in range(n):
+            synthesis.render_inputs(sv, views)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / n
+        out["render_inputs_B%d_views%d" % (Bs, views)] = {
+            "photos_per_s": Bs * views / dt, "ms_per_call": 1e3 * dt,
+            "note": "scene draws on the host in the reference's order + one K1 launch + device noise + clamp, whole batch"}
+    del a, b
     mixed = losses.MixedLoss(renderers.LocalRenderer())
     # BASELINE configs[3]: batch 16, mixed loss (the multi-view network's output has the same loss shapes); its 144 scene
     # rows ride in the launch's argument block like config 2's 72
@@ -318,9 +393,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     nccl = args.backend == "nccl"
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                          # --force-dist without a launcher: a rendezvous of one
+            os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if nccl:
             dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm
         else:
@@ -340,7 +419,7 @@ def main():
     batches = [(inp_h.to(dev).requires_grad_(True), tgt_h.to(dev))]
     for _ in range(1, max(1, args.rotate)):
         batches.append((synthetic_maps(gen, B, H).to(dev).requires_grad_(True), synthetic_maps(gen, B, H).to(dev)))
-    streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else None
+    streams = [torch.cuda.Stream(dev) for _ in range(max(2, args.streams))]
     loss_fn = losses.RenderingLoss(renderers.LocalRenderer())
     loss_fn.random_configuration_count = args.random_scenes
     loss_fn.specular_configuration_count = args.specular_scenes
@@ -373,7 +452,7 @@ def main():
         set_events = ext.set_timing_events
 
     counter = {"k": 0}
-    nb, ns = len(batches), (len(streams) if streams else 0)
+    nb, ns = len(batches), (args.streams if args.streams > 1 else 0)     # ns = 0: every step on the current stream
     set_stream = torch.cuda.set_stream
 
     def step():
@@ -417,18 +496,27 @@ def main():
     if ns:
         torch.cuda.set_stream(torch.cuda.default_stream(dev))
     _native.set_launch_hook(None)
+    per_rank = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if nccl else "cpu")
+        where = dev if nccl else "cpu"
+        mine = torch.tensor([elapsed, float(last.item()), float(distributed.rank_seed(313, rank))], dtype=torch.float64,
+                            device=where)
+        t = mine[:1].clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         mean_loss = distributed.global_mean(last.detach() if nccl else last.detach().cpu()).item()
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)            # for the record: each rank's own clock, last loss and scene seed
+        per_rank = {"elapsed_s": [float(e[0]) for e in every], "last_loss": [float(e[1]) for e in every],
+                    "scene_seed": [int(e[2]) for e in every]}
     else:
         mean_loss = last.item()
 
     kernel_ms = sorted(p[0].elapsed_time(p[1]) for p in ev if p is not None)
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
 
-    # ---- untimed follow-up phases (same process, same tensors): the shader clock under this load, and the kernel alone
+    # ---- untimed follow-up phases (same process, same tensors): the shader clock under this load, and the OTHER way of
+    # issuing the steps (the timed region ran them on one stream -> now alternating on two, and vice versa)
     state["i"] = -1
     clock_ghz, clock_note = None, "not measured"
     try:
@@ -448,46 +536,65 @@ def main():
                           "stream while the bench loop ran" % (ticks * 1e-5))
     except Exception as e:  # pragma: no cover
         clock_note = "probe failed: %r" % (e,)
-    # the kernel alone: one stream, one launch at a time, events around every 4th launch
     if ns:
         torch.cuda.set_stream(torch.cuda.default_stream(dev))
-    alone_steps = max(80, min(args.steps, 1024))
-    alone_stride = max(1, min(16, alone_steps // 5))
-    ev_alone = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % alone_stride == 0 else None
-                for i in range(alone_steps)]
-    saved_ns, ns = ns, 0
+    main_ns = ns
+    other_ns = 2 if main_ns == 0 else 0
+    other_steps = max(80, min(args.steps, 1024))
+    other_stride = max(1, min(16 if other_ns == 0 else 32, other_steps // 5))
+    ev_other = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % other_stride == 0 else None
+                for i in range(other_steps)]
+    ns = other_ns
     if ext is not None:
-        for pair in ev_alone:
+        for pair in ev_other:
             if pair is not None:
                 pair[0].record()
                 pair[1].record()
         torch.cuda.synchronize(dev)
-    ev, raw_ev = ev_alone, ([(p[0].cuda_event, p[1].cuda_event) if p is not None else None for p in ev_alone]
+    ev, raw_ev = ev_other, ([(p[0].cuda_event, p[1].cuda_event) if p is not None else None for p in ev_other]
                             if ext is not None else [])
     _native.set_launch_hook(hook)
-    t_alone = time.perf_counter()
-    for i in range(alone_steps):
+    for _ in range(32):                         # let the other issue pattern reach its steady state
+        step()
+    torch.cuda.synchronize(dev)
+    t_other = time.perf_counter()
+    for i in range(other_steps):
         state["i"] = i
         step()
     state["i"] = -1
     torch.cuda.synchronize(dev)
-    alone_ms_per_step = 1e3 * (time.perf_counter() - t_alone) / alone_steps
+    other_ms_per_step = 1e3 * (time.perf_counter() - t_other) / other_steps
     _native.set_launch_hook(None)
-    ns = saved_ns
-    alone_ms = sorted(p[0].elapsed_time(p[1]) for p in ev_alone if p is not None)
-    alone_ms_avg = sum(alone_ms) / len(alone_ms)
+    if ns:
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+    ns = main_ns
+    other_ms = sorted(p[0].elapsed_time(p[1]) for p in ev_other if p is not None)
+    other_ms_avg = sum(other_ms) / len(other_ms)
 
     if rank == 0:
         patches = world * B * args.steps
         ms_per_step = 1e3 * elapsed / args.steps
         alg_bytes = 144.0 * H * H * B                 # per launch: 36 planes x 4 B per patch
-        # time one launch takes out of the timed region.  With one stream that is the launch's own duration; with N
-        # streams launches overlap (each takes longer, event-bracketed, than its share of the GPU), so the share is what
-        # the roofline is priced with: timed region / launches.  Host-bound gaps count against the kernel (conservative).
-        n_streams = max(1, saved_ns)
+        n_streams = max(1, main_ns)
+        # the two ways of issuing the steps, whichever of them was the timed region
+        if main_ns == 0:
+            one = {"ms_per_step": ms_per_step, "kernel_ms": kernel_ms, "steps": args.steps, "leg": "the timed region"}
+            two = {"ms_per_step": other_ms_per_step, "kernel_ms": other_ms, "steps": other_steps, "streams": 2,
+                   "leg": "follow-up leg of rank 0, same process and tensors, right after the timed region"}
+        else:
+            one = {"ms_per_step": other_ms_per_step, "kernel_ms": other_ms, "steps": other_steps,
+                   "leg": "follow-up leg of rank 0, same process and tensors, right after the timed region"}
+            two = {"ms_per_step": ms_per_step, "kernel_ms": kernel_ms, "steps": args.steps, "streams": main_ns,
+                   "leg": "the timed region"}
+        one_kernel_avg = sum(one["kernel_ms"]) / len(one["kernel_ms"])
+        two_kernel_avg = sum(two["kernel_ms"]) / len(two["kernel_ms"])
+        # time one launch takes out of the timed region.  With one stream that is the launch's own event-bracketed
+        # duration; with N streams launches overlap (each takes longer, event-bracketed, than its share of the GPU), so
+        # the share is what the roofline is priced with: timed region / launches (host-bound gaps count against the kernel).
         share_ms = ms_per_step if n_streams > 1 else kernel_ms_avg
         achieved = alg_bytes / (share_ms * 1e-3) / 1e9
-        achieved_alone = alg_bytes / (alone_ms_avg * 1e-3) / 1e9
+        achieved_one = alg_bytes / (one_kernel_avg * 1e-3) / 1e9
+        achieved_two = alg_bytes / (two["ms_per_step"] * 1e-3) / 1e9
         traffic = valu_issue = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "k3_hbm_traffic.json")
         if os.path.exists(tpath):
@@ -504,15 +611,14 @@ def main():
                     if tj.get("valu_wave_instr_per_launch") and clock_ghz:
                         # what actually bounds K3: wave64 VALU instructions issued (PMC SQ_INSTS_VALU of the same
                         # kernel, profiles/) against the SIMD-32 issue peak of one per 2 cycles per SIMD
-                        # (MI355X_MICROARCH.md), 1024 SIMDs, at the clock the chip holds under this loop
+                        # (MI355X_MICROARCH.md), 1024 SIMDs, at the clock the chip holds under the timed region's loop
                         peak = 1024 * clock_ghz * 1e9 / 2.0
                         rate = tj["valu_wave_instr_per_launch"] / (share_ms * 1e-3)
-                        rate_alone = tj["valu_wave_instr_per_launch"] / (alone_ms_avg * 1e-3)
                         valu_issue = {"wave_instr_per_launch": tj["valu_wave_instr_per_launch"],
                                       "of_which_transcendental": tj.get("trans_wave_instr_per_launch"),
                                       "instr_count_source": traffic_source,
                                       "achieved_wave_instr_per_s": rate, "peak_wave_instr_per_s": peak,
-                                      "frac": rate / peak, "frac_one_launch_alone": rate_alone / peak,
+                                      "frac": rate / peak,
                                       "clock_GHz_under_load": clock_ghz, "clock_source": clock_note}
             except Exception:
                 traffic = valu_issue = traffic_source = None
@@ -520,15 +626,27 @@ def main():
         out = {
             "metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)",
             "value": patches / elapsed, "unit": "patches/s", "n_gpus": world,
+            "value_single_stream": world * B / (one["ms_per_step"] * 1e-3),
+            "value_two_streams_overlapped": world * B / (two["ms_per_step"] * 1e-3),
+            "value_note": ("`value` = the timed region, every step on ONE stream (what a training loop, serialised by its "
+                           "optimizer, gets); value_two_streams_overlapped = independent steps alternating on two streams, %s"
+                           % two["leg"]) if main_ns == 0 else
+                          ("`value` = the timed region with --streams %d: independent steps overlap on the GPU; "
+                           "value_single_stream = %s" % (main_ns, one["leg"])),
             "ranks_seen": dist.get_world_size() if dist is not None else 1,
+            "process_group": ("%s (%s), world size %d" % (args.backend, "RCCL" if nccl else "CPU transport, plumbing only",
+                                                          dist.get_world_size())) if dist is not None else None,
+            "per_rank": per_rank,
             "launch": "self-spawned" if os.environ.get("SVBRDF_SELF_SPAWNED") else
                       ("external launcher" if world > 1 else "single process"),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic %dx%d 12-channel SVBRDF maps, %d light/view "
-                                   "samples (%d random + %d specular), per-GPU batch %d, RenderingLoss fwd+bwd"
-                                   % (H, H, S, args.random_scenes, args.specular_scenes, B),
+                                   "samples (%d random + %d specular), per-GPU batch %d, RenderingLoss fwd+bwd, %s"
+                                   % (H, H, S, args.random_scenes, args.specular_scenes, B,
+                                      "one step at a time on one stream" if main_ns == 0 else
+                                      "TWO INDEPENDENT BATCHES IN FLIGHT: steps alternate on %d streams" % main_ns),
                        "global_batch": world * B, "H": H, "W": H, "scenes": S,
                        "parallelism": "batch-sharded x%d, no data-path collective" % world,
                        "streams_per_gpu": n_streams,
@@ -539,21 +657,28 @@ def main():
                        "working_set_MiB": working_set / 2.0 ** 20,
                        "working_set_note": "input + target + gradient of every batch visited round-robin; the Infinity "
                                            "Cache holds 256 MiB"},
-            "single_stream": {"patches_per_s": B / (alone_ms_per_step * 1e-3), "ms_per_step": alone_ms_per_step,
-                              "kernel_ms_avg": alone_ms_avg, "kernel_ms_median": alone_ms[len(alone_ms) // 2],
-                              "kernel_launches_timed": len(alone_ms), "steps": alone_steps,
-                              "note": "same process, same tensors, right after the timed region: every step on one stream, "
-                                      "events around a sample of the launches (every 16th at the default step count) -- the duration rocprofv3 --kernel-trace reports for "
-                                      "`bench.py --streams 1`"},
+            "single_stream": {"patches_per_s": B / (one["ms_per_step"] * 1e-3), "ms_per_step": one["ms_per_step"],
+                              "kernel_ms_avg": one_kernel_avg, "kernel_ms_median": one["kernel_ms"][len(one["kernel_ms"]) // 2],
+                              "kernel_launches_timed": len(one["kernel_ms"]), "steps": one["steps"], "leg": one["leg"],
+                              "note": "per GPU: every step on one stream, events around a sample of the launches -- the "
+                                      "duration rocprofv3 --kernel-trace reports for `bench.py --streams 1`"},
+            "two_streams_overlapped": {"patches_per_s": B / (two["ms_per_step"] * 1e-3), "ms_per_step": two["ms_per_step"],
+                                       "streams": two["streams"], "kernel_ms_avg_while_overlapped": two_kernel_avg,
+                                       "steps": two["steps"], "leg": two["leg"],
+                                       "roofline_frac_of_time_share": achieved_two / HBM_PEAK_GBPS,
+                                       "note": "per GPU: step k (launch + backward) on stream k mod 2; the steps are independent "
+                                               "batches, so one step's kernel fills the ramp and tail of the other's.  A "
+                                               "bench-loop property: not what one training loop gets"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac_single_launch": achieved_one / HBM_PEAK_GBPS,
                          "achieved_definition": ("algorithmic bytes per launch / time per launch in the timed region "
                                                  "(timed region / launches: launches on %d streams overlap)" % n_streams)
                                                 if n_streams > 1 else
                                                 "algorithmic bytes per launch / average event-bracketed launch duration",
                          "time_per_launch_ms": share_ms,
-                         "one_launch_alone": {"achieved": achieved_alone, "frac": achieved_alone / HBM_PEAK_GBPS,
-                                              "kernel_ms_avg": alone_ms_avg},
+                         "one_launch_alone": {"achieved": achieved_one, "frac": achieved_one / HBM_PEAK_GBPS,
+                                              "kernel_ms_avg": one_kernel_avg},
                          "frac_of_measured_copy_peak": achieved / 6290.0,   # MI355X_MICROARCH.md: float4 copy
                          "kernel": "%s<GRAD=true,L1=false,HEAD=false> (single launch: both shadings, log/L1, adjoint, loss finalise)"
                                    % ("k_rendering_loss_inl" if B * S <= _native.host_scenes_max_rows() else "k_rendering_loss"),

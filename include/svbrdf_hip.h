@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SVBRDF_ABI_VERSION 3
+#define SVBRDF_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define SVBRDF_API __attribute__((visibility("default")))
@@ -73,6 +73,20 @@ SVBRDF_API int svbrdf_render_fwd(const float *maps, const float *scenes, const f
 SVBRDF_API int svbrdf_render_bwd(const float *maps, const float *scenes, const float *xrow,
                       const float *grad_out, float *grad_maps,
                       int B, int S, int H, int W, void *stream);
+
+/* K1 / K2 with the scene rows in HOST memory -- what a reference-shaped `render(scene, svbrdf)` call has: the scene is a
+ * Python object (environment.py:4-16) and the reference uploads its three vectors with three synchronous H2D copies per
+ * call (renderers.py:79,91,98).  Here the rows travel BY VALUE in the launch's kernel-argument block: one dispatch per
+ * call, no copy command, nothing retained past return.  `scenes_host` (HOST pointer) holds
+ *     scenes_shared != 0 :  S rows, the SAME scenes for every map   (render's "one scene, B maps", renderers.py:98)
+ *     scenes_shared == 0 :  B*S rows, as svbrdf_render_fwd
+ * at most svbrdf_host_scenes_max_rows() of them (SVBRDF_ERR_DIMS beyond: upload the table and use the device entry).
+ * Same kernel bodies, bitwise the same results as svbrdf_render_fwd / svbrdf_render_bwd on an uploaded table. */
+SVBRDF_API int svbrdf_render_fwd_host_scenes(const float *maps, const float *scenes_host, int scenes_shared,
+                                             const float *xrow, float *out, int B, int S, int H, int W, void *stream);
+SVBRDF_API int svbrdf_render_bwd_host_scenes(const float *maps, const float *scenes_host, int scenes_shared,
+                                             const float *xrow, const float *grad_out, float *grad_maps,
+                                             int B, int S, int H, int W, void *stream);
 
 /* Ragged forms of K1 / K2 (SURVEY section 8b "arbitrary (map, scene) pairs in one launch"): R renders in all, grouped
  * by map -- the renders of map b are rows offsets[b] .. offsets[b+1]-1 of `scenes` [R,9] and of `out` / `grad_out`

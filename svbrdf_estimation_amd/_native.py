@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SVBRDF_HIP_LIB: load another build of the same ABI (ablation/experiment builds of tools/); default in-tree
 _SO = os.environ.get("SVBRDF_HIP_LIB") or os.path.join(_HERE, "lib", "libsvbrdf_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lock = threading.Lock()
 _lib = None
@@ -81,7 +81,10 @@ def _load():
         lib.svbrdf_host_scenes_max_rows.restype = ctypes.c_int
         lib.svbrdf_scale_inplace.argtypes = [_fp, _fp, ctypes.c_size_t, _fp]
         lib.svbrdf_scale_inplace.restype = ctypes.c_int
-        for name in ("svbrdf_make_xrow", "svbrdf_render_fwd", "svbrdf_render_bwd", "svbrdf_rendering_loss_fwd_bwd"):
+        lib.svbrdf_render_fwd_host_scenes.argtypes = [_fp, _fp, ctypes.c_int, _fp, _fp] + [ctypes.c_int] * 4 + [_fp]
+        lib.svbrdf_render_bwd_host_scenes.argtypes = [_fp, _fp, ctypes.c_int, _fp, _fp, _fp] + [ctypes.c_int] * 4 + [_fp]
+        for name in ("svbrdf_make_xrow", "svbrdf_render_fwd", "svbrdf_render_bwd", "svbrdf_rendering_loss_fwd_bwd",
+                     "svbrdf_render_fwd_host_scenes", "svbrdf_render_bwd_host_scenes"):
             getattr(lib, name).restype = ctypes.c_int
         v = lib.svbrdf_abi_version()
         if v != ABI_VERSION:
@@ -159,43 +162,83 @@ class _on_device:
 
 
 def _dims(maps, scenes):
+    """-> (B, S, H, W, shared): `scenes` is [B,S,9], or [S,9] = the same S scenes for every map (host tables only)"""
     if maps.dim() != 4 or maps.shape[1] != 12:
         raise ValueError("maps must be [B,12,H,W], got %s" % (tuple(maps.shape),))
     B, _, H, W = maps.shape
     if H != W:
         raise ValueError("H must equal W (got %dx%d): the reference transposes the x grid, renderers.py:75" % (H, W))
+    if scenes.dim() == 2 and not scenes.is_cuda and scenes.shape[1] == 9:
+        return B, scenes.shape[0], H, W, True
     if scenes.dim() != 3 or scenes.shape[0] != B or scenes.shape[2] != 9:
         raise ValueError("scenes must be [B,S,9], got %s for B=%d" % (tuple(scenes.shape), B))
-    return B, scenes.shape[1], H, W
+    return B, scenes.shape[1], H, W, False
+
+
+def _scene_table_for_launch(scenes, device):
+    """A HOST fp32 table that fits rides in the launch's kernel-argument block (-> host tensor, True); a larger one
+    is uploaded, shared rows expanded per map by the caller (-> device tensor, False); a device table passes."""
+    if not isinstance(scenes, torch.Tensor):
+        raise TypeError("scenes must be a torch.Tensor")
+    if scenes.dtype != torch.float32:
+        raise TypeError("scenes must be float32 (got %s)" % scenes.dtype)
+    if scenes.is_cuda:
+        return (scenes if scenes.is_contiguous() else scenes.contiguous()), False
+    rows = scenes.numel() // 9
+    if rows <= host_scenes_max_rows():
+        return (scenes if scenes.is_contiguous() else scenes.contiguous()), True
+    return upload_scene_table(scenes, device), False
 
 
 def render_fwd(maps, scenes):
-    """K1: maps [B,12,H,W], scenes [B,S,9] (device) -> renderings [B,S,3,H,W]."""
+    """K1: maps [B,12,H,W]; scenes [B,S,9] on the device, or on the HOST as [B,S,9] / [S,9] (the same S scenes for
+    every map): a host table of at most host_scenes_max_rows() rows travels with the launch (one dispatch, no copy
+    command).  -> renderings [B,S,3,H,W]."""
     _require_device_f32(maps, "maps")
-    _require_device_f32(scenes, "scenes")
-    maps, scenes = maps.contiguous(), scenes.contiguous()
-    B, S, H, W = _dims(maps, scenes)
+    if not maps.is_contiguous():
+        maps = maps.contiguous()
+    B, S, H, W, shared = _dims(maps, scenes)
+    if shared and S > host_scenes_max_rows():
+        scenes, shared = scenes.unsqueeze(0).expand(B, S, 9), False
+    table, on_host = _scene_table_for_launch(scenes, maps.device)
     out = torch.empty((B, S, 3, H, W), dtype=torch.float32, device=maps.device)
+    lib = _load()
     with _on_device(maps.device):
-        _check(_load().svbrdf_render_fwd(maps.data_ptr(), scenes.data_ptr(), xrow(maps.device, W).data_ptr(),
+        if on_host:
+            _check(lib.svbrdf_render_fwd_host_scenes(maps.data_ptr(), table.data_ptr(), int(shared),
+                                                     xrow(maps.device, W).data_ptr(), out.data_ptr(), B, S, H, W,
+                                                     _stream(maps.device)), "svbrdf_render_fwd_host_scenes")
+        else:
+            _check(lib.svbrdf_render_fwd(maps.data_ptr(), table.data_ptr(), xrow(maps.device, W).data_ptr(),
                                          out.data_ptr(), B, S, H, W, _stream(maps.device)), "svbrdf_render_fwd")
     return out
 
 
 def render_bwd(maps, scenes, grad_out):
-    """K2: adjoint of render_fwd -> grad_maps [B,12,H,W]."""
+    """K2: adjoint of render_fwd (same `scenes` forms) -> grad_maps [B,12,H,W]."""
     _require_device_f32(maps, "maps")
-    _require_device_f32(scenes, "scenes")
     _require_device_f32(grad_out, "grad_out")
-    maps, scenes, grad_out = maps.contiguous(), scenes.contiguous(), grad_out.contiguous()
-    B, S, H, W = _dims(maps, scenes)
-    if tuple(grad_out.shape) != (B, S, 3, H, W):
+    if not maps.is_contiguous():
+        maps = maps.contiguous()
+    if not grad_out.is_contiguous():
+        grad_out = grad_out.contiguous()
+    B, S, H, W, shared = _dims(maps, scenes)
+    if grad_out.numel() != B * S * 3 * H * W or grad_out.shape[-2:] != maps.shape[-2:]:
         raise ValueError("grad_out must be [B,S,3,H,W]")
+    if shared and S > host_scenes_max_rows():
+        scenes, shared = scenes.unsqueeze(0).expand(B, S, 9), False
+    table, on_host = _scene_table_for_launch(scenes, maps.device)
     grad = torch.empty_like(maps)
+    lib = _load()
     with _on_device(maps.device):
-        _check(_load().svbrdf_render_bwd(maps.data_ptr(), scenes.data_ptr(), xrow(maps.device, W).data_ptr(),
+        if on_host:
+            _check(lib.svbrdf_render_bwd_host_scenes(maps.data_ptr(), table.data_ptr(), int(shared),
+                                                     xrow(maps.device, W).data_ptr(), grad_out.data_ptr(), grad.data_ptr(),
+                                                     B, S, H, W, _stream(maps.device)), "svbrdf_render_bwd_host_scenes")
+        else:
+            _check(lib.svbrdf_render_bwd(maps.data_ptr(), table.data_ptr(), xrow(maps.device, W).data_ptr(),
                                          grad_out.data_ptr(), grad.data_ptr(), B, S, H, W, _stream(maps.device)),
-               "svbrdf_render_bwd")
+                   "svbrdf_render_bwd")
     return grad
 
 
@@ -278,7 +321,9 @@ def rendering_loss(input, target, scenes, eps=0.1, want_grad=True, l1_weight=0.0
     if target.device != input.device or (not host_scenes and scenes.device != input.device):
         raise ValueError("input, target and scenes must be on the same device")
     input, target, scenes = input.contiguous(), target.contiguous(), scenes.contiguous()
-    B, S, H, W = _dims(target, scenes)
+    B, S, H, W, shared = _dims(target, scenes)
+    if shared:
+        raise ValueError("the loss needs one scene table per batch item: scenes must be [B,S,9]")
     lib = _load()
     nbytes = lib.svbrdf_rendering_loss_workspace_bytes(B, S, H, W)
     ws = _workspace(input.device, nbytes)

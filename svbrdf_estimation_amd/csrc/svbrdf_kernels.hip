@@ -553,6 +553,11 @@ __device__ __forceinline__ void load_scene(const float *__restrict__ p, float sc
     for (int i = 0; i < 9; ++i) sc[i] = p[i];
 }
 
+// scene rows passed BY VALUE in a launch's kernel-argument block (see k_rendering_loss_inl)
+struct SceneBlock {
+    float v[SVBRDF_HOST_SCENES_MAX_ROWS * 9];
+};
+
 // ------------------------------------------------------------------------------------------
 // K1: render forward.  grid = (ceil(H*W / (256*VEC)), B); S renders per map in one pass.
 // ------------------------------------------------------------------------------------------
@@ -585,13 +590,13 @@ __device__ __forceinline__ void render_fwd_loop(const MapK mk[VEC], const float 
 }
 
 // `offsets` (or null): ragged form, the renders of map b are rows offsets[b] .. offsets[b+1] of scenes / out
-// (any number per map, zero included) instead of the regular S per map.
+// (any number per map, zero included) instead of the regular S per map.  `shared`: ONE list of S scenes for every
+// map (rows 0 .. S-1 of `scenes`) instead of S rows per map -- LocalRenderer.render's "one scene, B maps"
+// (renderers.py:98) without materialising B copies of the row.
 template <int VEC>
-__global__ __launch_bounds__(kThreads) void k_render_fwd(const float *__restrict__ maps,
-                                                         const float *__restrict__ scenes,
-                                                         const float *__restrict__ xrow,
-                                                         float *__restrict__ out, const int *__restrict__ offsets,
-                                                         int S, int H, int W)
+__device__ __forceinline__ void render_fwd_body(const float *__restrict__ maps, const float *__restrict__ scenes,
+                                                const float *__restrict__ xrow, float *__restrict__ out,
+                                                const int *__restrict__ offsets, bool shared, int S, int H, int W)
 {
     const size_t plane = (size_t)H * W;
     const size_t pix = ((size_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
@@ -615,10 +620,34 @@ __global__ __launch_bounds__(kThreads) void k_render_fwd(const float *__restrict
         first = (size_t)offsets[b];
         S = offsets[b + 1] - offsets[b];
     }
-    const float *__restrict__ scp = scenes + first * 9;
+    const float *__restrict__ scp = scenes + (shared ? 0 : first * 9);
     float *__restrict__ o = out + first * 3 * plane + pix;
     if (__all(tied)) render_fwd_loop<VEC, 1>(mk, x, y, scp, o, plane, S);      // wave-uniform branch
     else render_fwd_loop<VEC, 3>(mk, x, y, scp, o, plane, S);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void k_render_fwd(const float *__restrict__ maps,
+                                                         const float *__restrict__ scenes,
+                                                         const float *__restrict__ xrow,
+                                                         float *__restrict__ out, const int *__restrict__ offsets,
+                                                         int shared, int S, int H, int W)
+{
+    render_fwd_body<VEC>(maps, scenes, xrow, out, offsets, shared != 0, S, H, W);
+}
+
+// scene rows BY VALUE in the kernel-argument block (see SceneBlock below: the table is the first argument and is
+// read through the kernarg segment pointer with the same wave-uniform scalar loads).  A reference-shaped
+// `render(scene, svbrdf)` call (renderers.py:67-104: three synchronous H2D copies per call, :79,91,98) is then ONE
+// dispatch with no copy command in front of it.
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void k_render_fwd_inl([[maybe_unused]] const SceneBlock table,
+                                                             const float *__restrict__ maps,
+                                                             const float *__restrict__ xrow, float *__restrict__ out,
+                                                             int shared, int S, int H, int W)
+{
+    const float *__restrict__ rows = (const float *)__builtin_amdgcn_kernarg_segment_ptr();
+    render_fwd_body<VEC>(maps, rows, xrow, out, nullptr, shared != 0, S, H, W);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -651,12 +680,10 @@ __device__ __forceinline__ void render_bwd_loop(const MapK mk[VEC], const float 
 }
 
 template <int VEC>
-__global__ __launch_bounds__(kThreads) void k_render_bwd(const float *__restrict__ maps,
-                                                         const float *__restrict__ scenes,
-                                                         const float *__restrict__ xrow,
-                                                         const float *__restrict__ grad_out,
-                                                         float *__restrict__ grad_maps, const int *__restrict__ offsets,
-                                                         int S, int H, int W)
+__device__ __forceinline__ void render_bwd_body(const float *__restrict__ maps, const float *__restrict__ scenes,
+                                                const float *__restrict__ xrow, const float *__restrict__ grad_out,
+                                                float *__restrict__ grad_maps, const int *__restrict__ offsets,
+                                                bool shared, int S, int H, int W)
 {
     const size_t plane = (size_t)H * W;
     const size_t pix = ((size_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
@@ -683,11 +710,33 @@ __global__ __launch_bounds__(kThreads) void k_render_bwd(const float *__restrict
         first = (size_t)offsets[b];
         S = offsets[b + 1] - offsets[b];
     }
-    const float *__restrict__ scp = scenes + first * 9;
+    const float *__restrict__ scp = scenes + (shared ? 0 : first * 9);
     const float *__restrict__ go = grad_out + first * 3 * plane + pix;
     if (__all(tied)) render_bwd_loop<VEC, 1>(mk, x, y, scp, go, plane, S, acc);
     else render_bwd_loop<VEC, 3>(mk, x, y, scp, go, plane, S, acc);
     store_grads<VEC, true>(grad_maps + (size_t)b * 12 * plane, plane, pix, acc);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void k_render_bwd(const float *__restrict__ maps,
+                                                         const float *__restrict__ scenes,
+                                                         const float *__restrict__ xrow,
+                                                         const float *__restrict__ grad_out,
+                                                         float *__restrict__ grad_maps, const int *__restrict__ offsets,
+                                                         int shared, int S, int H, int W)
+{
+    render_bwd_body<VEC>(maps, scenes, xrow, grad_out, grad_maps, offsets, shared != 0, S, H, W);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void k_render_bwd_inl([[maybe_unused]] const SceneBlock table,
+                                                             const float *__restrict__ maps,
+                                                             const float *__restrict__ xrow,
+                                                             const float *__restrict__ grad_out,
+                                                             float *__restrict__ grad_maps, int shared, int S, int H, int W)
+{
+    const float *__restrict__ rows = (const float *)__builtin_amdgcn_kernarg_segment_ptr();
+    render_bwd_body<VEC>(maps, rows, xrow, grad_out, grad_maps, nullptr, shared != 0, S, H, W);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -775,11 +824,12 @@ __device__ __forceinline__ void loss_pixel_scene(const VConst &K, const Geom &g,
             // lg = log2(at/ai) = -(log(ai) - log(at))/ln2.  The loss sums |lg| (scaled by ln2 ONCE, after the scene
             // loop); d|delta|/d ri = sign(delta)/(N ai) = -sign(lg) nc/b: the magnitude nc*ib takes lg's sign bit with
             // one v_and_or, and the minus rides as a source modifier on the product that consumes it.  sign(0) = 0 as in
-            // torch: equal operands select magnitude 0 (and lg = 0) explicitly.
-            const bool differ = b[k] != bt[k];
-            const float lg = differ ? log2_(bt[k] * ib[k]) : 0.0f;
+            // torch: equal operands select lg = 0 explicitly, and lg == 0 -- equal operands, or a quotient of unequal
+            // ones that rounds to exactly 1 -- selects magnitude 0 (a +0 there would otherwise always read as "input
+            // darker": a systematic sign at near-ties where the reference's rounded log difference gives 0).
+            const float lg = (b[k] != bt[k]) ? log2_(bt[k] * ib[k]) : 0.0f;
             lsum += fabsf(lg);
-            const float mag = differ ? nc * ib[k] : 0.0f;
+            const float mag = (lg != 0.0f) ? nc * ib[k] : 0.0f;
             g_rad[k] = -__builtin_bit_cast(float, __builtin_bit_cast(unsigned, mag) | (__builtin_bit_cast(unsigned, lg) & 0x80000000u));
         }
     }
@@ -818,11 +868,10 @@ __device__ __forceinline__ void loss_pixel_scene_by_channel(const VConst &K, con
         const float ri = fi * (g.E[k] * di.LNp);
         const float b = fma_(ri, c, ec), bt = fma_(rt, c, ec);
         const float ib = rcp_(b);
-        const bool differ = b != bt;
-        const float lg = differ ? log2_(bt * ib) : 0.0f;                // see loss_pixel_scene
+        const float lg = (b != bt) ? log2_(bt * ib) : 0.0f;             // see loss_pixel_scene
         lsum += fabsf(lg);
         if (WITH_GRAD) {
-            const float mag = differ ? nc * ib : 0.0f;
+            const float mag = (lg != 0.0f) ? nc * ib : 0.0f;
             const float g_rad = -__builtin_bit_cast(float, __builtin_bit_cast(unsigned, mag) | (__builtin_bit_cast(unsigned, lg) & 0x80000000u));
             const float gE = g_rad * g.E[k];
             const float g_f = gE * di.LNp;
@@ -1165,8 +1214,13 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         // for NaN/inf) nor reach the arrival count in the word's top bits: it contributes 0 and raises the sticky
         // non-finite flag next to the ticket counter instead, and the finisher reports NaN -- as the reference's
         // log/L1 chain would (isfinite(loss) guards keep working) -- and leaves the scratch zeroed as always.
+        // The bound is per workgroup: the slot_blocks partial sums of one slot must not carry into the arrival count
+        // together either, so each stays below 2^47 / slot_blocks -- still above every legitimate value (the host picks
+        // the scale so that slot_blocks maximal partial sums fit 2^47), but finite absurd maps (|dlog| of 70-110 per
+        // term) can no longer add up past bit 48, keep the finisher from firing and leave the scratch dirty.
         const float scaled = fma_(t, fixed_scale, 0.5f);
-        const bool finite = scaled >= 0.0f && scaled < 140737488355328.0f;       // 2^47; false for NaN
+        const float limit = 140737488355328.0f * 0.999f * rcp_((float)slot_blocks);     // 2^47 / slot_blocks
+        const bool finite = scaled >= 0.0f && scaled < limit;                            // false for NaN
         const unsigned long long fixed = finite ? (unsigned long long)scaled : 0ULL;
         if (!finite) {
             atomicOr(&ws[kLossSlots], kLossNonFiniteFlag);
@@ -1223,10 +1277,6 @@ __global__ SVBRDF_K3_ATTRS void k_rendering_loss(const float *__restrict__ input
 // Capacity: 288 rows (10,368 bytes) -- configs[3] (16 x 9 rows) and config 5 at batch 8 (8 x 32) fit; the
 // runtime takes argument blocks of 32 KB and more on gfx950 (tools: a by-value struct of 32,000 bytes launches and
 // reads back correctly), and marshalling 10 KB costs the launch ~0.2 us.
-struct SceneBlock {
-    float v[SVBRDF_HOST_SCENES_MAX_ROWS * 9];
-};
-
 // `table` is the FIRST argument, i.e. it sits at offset 0 of the kernarg segment, and is read through
 // the segment pointer: taking the address of the by-value parameter itself makes the compiler
 // copy the whole block into scratch in the adjoint variants (seen in the resource report).
@@ -1504,8 +1554,9 @@ int svbrdf_make_xrow(float *xrow_host, int W)
     return 0;
 }
 
+// `host_rows` > 0: `scenes` is a HOST table of that many rows and travels by value in the argument block
 static int render_fwd_impl(const float *maps, const float *scenes, const float *xrow, float *out, const int *offsets,
-                           int B, int S, int H, int W, void *stream)
+                           int shared, int host_rows, int B, int S, int H, int W, void *stream)
 {
     if (!maps || !scenes || !xrow || !out) return fail(SVBRDF_ERR_NULL, "render_fwd: null pointer");
     if (int e = check_dims(B, S, H, W)) return e;
@@ -1514,16 +1565,43 @@ static int render_fwd_impl(const float *maps, const float *scenes, const float *
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int vec = pick_vec(env_vec("SVBRDF_K1_VEC", 4), W, {maps, xrow, out});
     const dim3 grid = grid_for(B, H, W, vec), block(kThreads);
-    if (vec == 4) hipLaunchKernelGGL(k_render_fwd<4>, grid, block, 0, st, maps, scenes, xrow, out, offsets, S, H, W);
-    else if (vec == 2) hipLaunchKernelGGL(k_render_fwd<2>, grid, block, 0, st, maps, scenes, xrow, out, offsets, S, H, W);
-    else hipLaunchKernelGGL(k_render_fwd<1>, grid, block, 0, st, maps, scenes, xrow, out, offsets, S, H, W);
+    if (host_rows > 0) {
+        SceneBlock block_arg;      // only the first host_rows rows are ever read
+        std::memcpy(block_arg.v, scenes, (size_t)host_rows * 9 * sizeof(float));
+        if (vec == 4) hipLaunchKernelGGL(k_render_fwd_inl<4>, grid, block, 0, st, block_arg, maps, xrow, out, shared, S, H, W);
+        else if (vec == 2) hipLaunchKernelGGL(k_render_fwd_inl<2>, grid, block, 0, st, block_arg, maps, xrow, out, shared, S, H, W);
+        else hipLaunchKernelGGL(k_render_fwd_inl<1>, grid, block, 0, st, block_arg, maps, xrow, out, shared, S, H, W);
+        return launch_status("render_fwd_host_scenes launch");
+    }
+    if (vec == 4) hipLaunchKernelGGL(k_render_fwd<4>, grid, block, 0, st, maps, scenes, xrow, out, offsets, shared, S, H, W);
+    else if (vec == 2) hipLaunchKernelGGL(k_render_fwd<2>, grid, block, 0, st, maps, scenes, xrow, out, offsets, shared, S, H, W);
+    else hipLaunchKernelGGL(k_render_fwd<1>, grid, block, 0, st, maps, scenes, xrow, out, offsets, shared, S, H, W);
     return launch_status("render_fwd launch");
+}
+
+static int host_rows_for(const char *who, int scenes_shared, int B, int S, int *rows)
+{
+    const long long n = scenes_shared ? (long long)S : (long long)B * S;
+    if (n > SVBRDF_HOST_SCENES_MAX_ROWS)
+        return fail(SVBRDF_ERR_DIMS, who);
+    *rows = (int)n;
+    return 0;
 }
 
 int svbrdf_render_fwd(const float *maps, const float *scenes, const float *xrow, float *out,
                       int B, int S, int H, int W, void *stream)
 {
-    return render_fwd_impl(maps, scenes, xrow, out, nullptr, B, S, H, W, stream);
+    return render_fwd_impl(maps, scenes, xrow, out, nullptr, 0, 0, B, S, H, W, stream);
+}
+
+int svbrdf_render_fwd_host_scenes(const float *maps, const float *scenes_host, int scenes_shared, const float *xrow,
+                                  float *out, int B, int S, int H, int W, void *stream)
+{
+    if (int e = check_dims(B, S, H, W)) return e;
+    int rows = 0;
+    if (int e = host_rows_for("render_fwd_host_scenes: the table exceeds SVBRDF_HOST_SCENES_MAX_ROWS (upload it and use "
+                              "svbrdf_render_fwd)", scenes_shared, B, S, &rows)) return e;
+    return render_fwd_impl(maps, scenes_host, xrow, out, nullptr, scenes_shared != 0, rows, B, S, H, W, stream);
 }
 
 int svbrdf_render_fwd_ragged(const float *maps, const float *scenes, const int *offsets, const float *xrow, float *out,
@@ -1532,11 +1610,12 @@ int svbrdf_render_fwd_ragged(const float *maps, const float *scenes, const int *
     if (!offsets) return fail(SVBRDF_ERR_NULL, "render_fwd_ragged: offsets is null");
     if (R < 0) return fail(SVBRDF_ERR_DIMS, "render_fwd_ragged: R must be >= 0");
     if (R == 0) return check_dims(B, 1, H, W);          // nothing to render
-    return render_fwd_impl(maps, scenes, xrow, out, offsets, B, 1, H, W, stream);
+    return render_fwd_impl(maps, scenes, xrow, out, offsets, 0, 0, B, 1, H, W, stream);
 }
 
 static int render_bwd_impl(const float *maps, const float *scenes, const float *xrow, const float *grad_out,
-                           float *grad_maps, const int *offsets, int B, int S, int H, int W, void *stream)
+                           float *grad_maps, const int *offsets, int shared, int host_rows, int B, int S, int H, int W,
+                           void *stream)
 {
     if (!maps || !scenes || !xrow || !grad_out || !grad_maps) return fail(SVBRDF_ERR_NULL, "render_bwd: null pointer");
     if (int e = check_dims(B, S, H, W)) return e;
@@ -1546,16 +1625,34 @@ static int render_bwd_impl(const float *maps, const float *scenes, const float *
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int vec = pick_vec(env_vec("SVBRDF_K2_VEC", 2), W, {maps, xrow, grad_out, grad_maps});
     const dim3 grid = grid_for(B, H, W, vec), block(kThreads);
-    if (vec == 4) hipLaunchKernelGGL(k_render_bwd<4>, grid, block, 0, st, maps, scenes, xrow, grad_out, grad_maps, offsets, S, H, W);
-    else if (vec == 2) hipLaunchKernelGGL(k_render_bwd<2>, grid, block, 0, st, maps, scenes, xrow, grad_out, grad_maps, offsets, S, H, W);
-    else hipLaunchKernelGGL(k_render_bwd<1>, grid, block, 0, st, maps, scenes, xrow, grad_out, grad_maps, offsets, S, H, W);
+    if (host_rows > 0) {
+        SceneBlock block_arg;
+        std::memcpy(block_arg.v, scenes, (size_t)host_rows * 9 * sizeof(float));
+        if (vec == 4) hipLaunchKernelGGL(k_render_bwd_inl<4>, grid, block, 0, st, block_arg, maps, xrow, grad_out, grad_maps, shared, S, H, W);
+        else if (vec == 2) hipLaunchKernelGGL(k_render_bwd_inl<2>, grid, block, 0, st, block_arg, maps, xrow, grad_out, grad_maps, shared, S, H, W);
+        else hipLaunchKernelGGL(k_render_bwd_inl<1>, grid, block, 0, st, block_arg, maps, xrow, grad_out, grad_maps, shared, S, H, W);
+        return launch_status("render_bwd_host_scenes launch");
+    }
+    if (vec == 4) hipLaunchKernelGGL(k_render_bwd<4>, grid, block, 0, st, maps, scenes, xrow, grad_out, grad_maps, offsets, shared, S, H, W);
+    else if (vec == 2) hipLaunchKernelGGL(k_render_bwd<2>, grid, block, 0, st, maps, scenes, xrow, grad_out, grad_maps, offsets, shared, S, H, W);
+    else hipLaunchKernelGGL(k_render_bwd<1>, grid, block, 0, st, maps, scenes, xrow, grad_out, grad_maps, offsets, shared, S, H, W);
     return launch_status("render_bwd launch");
 }
 
 int svbrdf_render_bwd(const float *maps, const float *scenes, const float *xrow, const float *grad_out,
                       float *grad_maps, int B, int S, int H, int W, void *stream)
 {
-    return render_bwd_impl(maps, scenes, xrow, grad_out, grad_maps, nullptr, B, S, H, W, stream);
+    return render_bwd_impl(maps, scenes, xrow, grad_out, grad_maps, nullptr, 0, 0, B, S, H, W, stream);
+}
+
+int svbrdf_render_bwd_host_scenes(const float *maps, const float *scenes_host, int scenes_shared, const float *xrow,
+                                  const float *grad_out, float *grad_maps, int B, int S, int H, int W, void *stream)
+{
+    if (int e = check_dims(B, S, H, W)) return e;
+    int rows = 0;
+    if (int e = host_rows_for("render_bwd_host_scenes: the table exceeds SVBRDF_HOST_SCENES_MAX_ROWS (upload it and use "
+                              "svbrdf_render_bwd)", scenes_shared, B, S, &rows)) return e;
+    return render_bwd_impl(maps, scenes_host, xrow, grad_out, grad_maps, nullptr, scenes_shared != 0, rows, B, S, H, W, stream);
 }
 
 int svbrdf_render_bwd_ragged(const float *maps, const float *scenes, const int *offsets, const float *xrow,
@@ -1565,7 +1662,7 @@ int svbrdf_render_bwd_ragged(const float *maps, const float *scenes, const int *
     if (R < 0) return fail(SVBRDF_ERR_DIMS, "render_bwd_ragged: R must be >= 0");
     // R == 0 still launches: every map's gradient is written (zeros)
     const float *go = (R == 0 && !grad_out) ? maps : grad_out, *sc = (R == 0 && !scenes) ? maps : scenes;
-    return render_bwd_impl(maps, sc, xrow, go, grad_maps, offsets, B, 1, H, W, stream);
+    return render_bwd_impl(maps, sc, xrow, go, grad_maps, offsets, 0, 0, B, 1, H, W, stream);
 }
 
 size_t svbrdf_rendering_loss_workspace_bytes(int B, int S, int H, int W)

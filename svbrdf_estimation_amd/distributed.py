@@ -30,6 +30,25 @@ def shard(tensor, rank, world_size):
     return tensor[lo:hi]
 
 
+class ContiguousShardSampler:
+    """Sampler for verification runs: global batch k is the index block [k*G, (k+1)*G), G = per_rank_batch * world,
+    and rank r reads its contiguous slice of it, unshuffled -- so that N ranks together see exactly the batches one
+    process with batch G sees, in the same item order (DistributedSampler interleaves the ranks' items)."""
+
+    def __init__(self, length, per_rank_batch, rank, world_size):
+        self.per, self.rank, self.world = int(per_rank_batch), int(rank), int(world_size)
+        self.batches = int(length) // (self.per * self.world)
+
+    def __len__(self):
+        return self.batches * self.per
+
+    def __iter__(self):
+        G = self.per * self.world
+        for k in range(self.batches):
+            lo = k * G + self.rank * self.per
+            yield from range(lo, lo + self.per)
+
+
 def global_mean(local_mean):
     """mean over ranks of a per-rank mean (equal shards) -- for logging only."""
     import torch.distributed as dist

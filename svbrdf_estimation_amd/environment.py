@@ -154,13 +154,21 @@ def generate_specular_scenes(count):
 
 
 def _triple(v, what):
-    t = torch.as_tensor(v, dtype=torch.float32).detach().reshape(-1).cpu()
-    if t.numel() != 3:
-        raise ValueError("%s must have 3 components, got %d" % (what, t.numel()))
-    return t
+    """3-sequence, ndarray or tensor -> three python floats (ONE host read for a tensor, whatever device it is on)"""
+    if isinstance(v, torch.Tensor):
+        vals = v.detach().reshape(-1).tolist()
+    elif isinstance(v, (list, tuple)):
+        vals = [float(x) for x in v]
+    else:
+        import numpy as np
+        vals = np.asarray(v, dtype=np.float64).reshape(-1).tolist()
+    if len(vals) != 3:
+        raise ValueError("%s must have 3 components, got %d" % (what, len(vals)))
+    return vals
 
 
 def scene_to_row(scene):
-    """any object with .camera.pos, .light.pos, .light.color (lists, ndarrays or tensors) -> [9]"""
-    return torch.cat((_triple(scene.camera.pos, "camera.pos"), _triple(scene.light.pos, "light.pos"),
-                      _triple(scene.light.color, "light.color")))
+    """any object with .camera.pos, .light.pos, .light.color (lists, ndarrays or tensors) -> host fp32 [9]
+    (float32 rounding of the values as ``torch.Tensor(...)`` does it, renderers.py:79,91,98)"""
+    return torch.tensor(_triple(scene.camera.pos, "camera.pos") + _triple(scene.light.pos, "light.pos")
+                        + _triple(scene.light.color, "light.color"), dtype=torch.float32)

@@ -47,19 +47,21 @@ def rank_environment(rank, world, port, base=None):
     return env
 
 
-def spawn_ranks(script, argv, world, timeout_s=None, poll_s=0.05):
+def spawn_ranks(script, argv, world, timeout_s=None, poll_s=0.05, grace_s=10.0):
     """Start `world` rank processes of ``python script argv...``; relay rank 0's stdout to ours (the
     other ranks' stdout goes to stderr), wait for all of them and return the largest exit code.
-    When one rank fails the others are terminated (exact PIDs) instead of being left in a barrier."""
+    When one rank fails the others are terminated (exact PIDs) instead of being left in a barrier; a rank
+    that has not exited `grace_s` seconds after its SIGTERM (wedged in a collective, say) is killed."""
     if world < 1:
         raise ValueError("world must be >= 1")
-    port = free_port()
-    procs = []
+    port = free_port()       # closed again before the ranks bind it: another process could take it in between, in which
+    procs = []               # case rank 0's rendezvous fails loudly and the parent exits non-zero (no silent retry)
     for rank in range(world):
         out = None if rank == 0 else sys.stderr     # rank 0 inherits our stdout: its JSON line is ours
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=rank_environment(rank, world, port),
                                       stdout=out, stderr=None))
     deadline = None if timeout_s is None else time.monotonic() + timeout_s
+    kill_at = None                                   # set when the ranks have been sent SIGTERM
     worst = 0
     try:
         pending = set(range(world))
@@ -69,12 +71,13 @@ def spawn_ranks(script, argv, world, timeout_s=None, poll_s=0.05):
                 if rc is None:
                     continue
                 pending.discard(r)
-                if rc != 0:
+                if rc != 0 and kill_at is None:
                     worst = max(worst, rc if rc > 0 else 1)
                     print("[launch] rank %d exited with code %d; stopping the other ranks" % (r, rc),
                           file=sys.stderr, flush=True)
                     for o in sorted(pending):
                         procs[o].terminate()
+                    kill_at = time.monotonic() + grace_s
             if deadline is not None and time.monotonic() > deadline and pending:
                 print("[launch] timeout after %.0f s; stopping ranks %s" % (timeout_s, sorted(pending)),
                       file=sys.stderr, flush=True)
@@ -82,6 +85,14 @@ def spawn_ranks(script, argv, world, timeout_s=None, poll_s=0.05):
                     procs[o].terminate()
                 worst = max(worst, 124)
                 deadline = None
+                kill_at = time.monotonic() + grace_s
+            if kill_at is not None and time.monotonic() > kill_at and pending:
+                print("[launch] ranks %s ignored SIGTERM for %.0f s; killing them" % (sorted(pending), grace_s),
+                      file=sys.stderr, flush=True)
+                for o in sorted(pending):
+                    procs[o].kill()
+                worst = max(worst, 1)
+                kill_at = None
             if pending:
                 time.sleep(poll_s)
     finally:

@@ -19,19 +19,23 @@ from . import _native, environment
 
 
 class _RenderFunction(torch.autograd.Function):
-    """maps [B,12,H,W], scenes [B,S,9] (device, no grad) -> [B,S,3,H,W]"""
+    """maps [B,12,H,W]; scenes (no grad) [B,S,9] on the device, or on the host as [B,S,9] / [S,9] (shared by all
+    maps): a small host table rides in the launch's argument block (_native.render_fwd) -> [B,S,3,H,W]"""
 
     @staticmethod
     def forward(ctx, maps, scenes):
-        maps = maps.contiguous()
-        ctx.save_for_backward(maps, scenes)
+        if not maps.is_contiguous():
+            maps = maps.contiguous()
+        ctx.save_for_backward(maps)
+        ctx.scenes = scenes                     # not a graph tensor: kept as a plain attribute
         return _native.render_fwd(maps, scenes)
 
     @staticmethod
     def backward(ctx, grad_out):
-        maps, scenes = ctx.saved_tensors
-        grad_maps = _native.render_bwd(maps, scenes, grad_out.contiguous()) if ctx.needs_input_grad[0] else None
-        return grad_maps, None
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        maps, = ctx.saved_tensors
+        return _native.render_bwd(maps, ctx.scenes, grad_out), None
 
 
 class LocalRenderer:
@@ -46,19 +50,17 @@ class LocalRenderer:
             maps = svbrdf
         else:
             raise ValueError("svbrdf must be [12,H,W] or [B,12,H,W], got %s" % (tuple(svbrdf.shape),))
-        B = maps.shape[0]
-        row = environment.scene_to_row(scene)                      # host, 9 floats
-        table = row.view(1, 1, 9).expand(B, 1, 9).contiguous()
-        table = table.to(maps.device, non_blocking=True) if maps.is_cuda else table
-        out = _RenderFunction.apply(maps, table)                   # raises on non-ROCm tensors
-        return out.view(B, 3, maps.shape[-2], maps.shape[-1])
+        # the scene's nine floats stay on the host and travel with the launch: one dispatch per call, no H2D copy
+        # (the reference uploads camera, light and colour with three synchronous copies, renderers.py:79,91,98)
+        row = environment.scene_to_row(scene).view(1, 9)           # one scene, shared by every map of the batch
+        out = _RenderFunction.apply(maps, row)                     # raises on non-ROCm tensors
+        return out.view(maps.shape[0], 3, maps.shape[-2], maps.shape[-1])
 
     def render_many(self, scene_table, svbrdf):
         """scene_table [S,9] (shared by all maps) or [B,S,9]; svbrdf [B,12,H,W] -> [B,S,3,H,W]."""
         if svbrdf.dim() != 4:
             raise ValueError("render_many expects svbrdf [B,12,H,W]")
         table = torch.as_tensor(scene_table, dtype=torch.float32)
-        if table.dim() == 2:
+        if table.is_cuda and table.dim() == 2:
             table = table.unsqueeze(0).expand(svbrdf.shape[0], -1, -1)
-        table = table.contiguous().to(svbrdf.device, non_blocking=True)
         return _RenderFunction.apply(svbrdf, table)

@@ -72,8 +72,8 @@ def render_inputs(svbrdf, count, use_augmentation=True, noise="device"):
                 std = noise_std()
                 per_image.append(torch.zeros(1, 3, H, W).normal_(mean=0.0, std=std))
             fields.append(torch.cat(per_image, dim=0))
-    table = torch.stack(tables, dim=0).to(maps.device, non_blocking=True)
-    out = _native.render_fwd(maps.detach(), table)                      # K1: [B,count,3,H,W]
+    # K1: [B,count,3,H,W]; the host table travels with the launch when it fits the argument block (pinned ring otherwise)
+    out = _native.render_fwd(maps.detach(), torch.stack(tables, dim=0))
     if noise == "cpu":
         out = out + torch.stack(fields, dim=0).to(maps.device, non_blocking=True)
     elif noise == "device":

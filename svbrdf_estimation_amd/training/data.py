@@ -55,8 +55,11 @@ class TiledPngDataset(torch.utils.data.Dataset):
     ``mix_materials`` only for ``image_count == 0`` (dataset.py:29-32): a partner sample is picked with python's
                     ``random.randrange`` and a blend weight with ``torch`` U(0.1, 0.9) (dataset.py:52-56, :144) --
                     same generators, same order -- and returned as ``svbrdf_other`` / ``mix_alpha``; the blend
-                    itself runs on the GPU for the whole batch (``apply_mixing`` -> kernel K4).  Mixing commutes
-                    with cropping exactly; with 'resize' it is applied after the resize (the reference blends first).
+                    itself runs on the GPU for the whole batch (``apply_mixing`` -> kernel K4).  The reference
+                    blends at full resolution BEFORE it scales (dataset.py:52-73).  A crop commutes with the
+                    per-pixel blend exactly, a bilinear resize does not (the blended normals are renormalised), so
+                    with 'resize' the item carries both materials centre-cropped but UNRESIZED plus ``resize_to``,
+                    and ``apply_mixing`` blends at that resolution and resizes afterwards, in the reference's order.
     ``no_svbrdf``   photos only: a flat dummy SVBRDF (normals (0,0,1), everything else 0), dataset.py:116-124.
 
     Returns {'inputs': [n,3,S,S], 'svbrdf': [12,S,S]} (+ 'svbrdf_other', 'mix_alpha' when mixing)."""
@@ -92,8 +95,9 @@ class TiledPngDataset(torch.utils.data.Dataset):
         keep = min(self.image_count, self.used)
         return photos[self.image_count - keep:self.image_count], svbrdf
 
-    def _scale(self, photos, svbrdfs):
-        """the reference's crop / resize of the photos and of every SVBRDF in `svbrdfs` with ONE anchor"""
+    def _scale(self, photos, svbrdfs, resize_maps=True):
+        """the reference's crop / resize of the photos and of every SVBRDF in `svbrdfs` with ONE anchor;
+        ``resize_maps=False`` stops after the centre crop of the maps (material mixing comes before the resize)"""
         height, width = svbrdfs[0].shape[-2:]
         S = self.image_size
         if self.scale_mode == "resize":
@@ -107,7 +111,8 @@ class TiledPngDataset(torch.utils.data.Dataset):
                 photos = interp(photos, size=(S, S), mode="bilinear")
             else:
                 photos = photos.new_zeros((0, 3, S, S))
-            svbrdfs = [interp(m.unsqueeze(0), size=(S, S), mode="bilinear").squeeze(0) for m in svbrdfs]
+            if resize_maps:
+                svbrdfs = [interp(m.unsqueeze(0), size=(S, S), mode="bilinear").squeeze(0) for m in svbrdfs]
         else:
             anchor = (0, 0)
             if self.random_crop:
@@ -124,12 +129,15 @@ class TiledPngDataset(torch.utils.data.Dataset):
             other = random.randrange(0, len(self))                                    # dataset.py:54
             maps.append(self.read_sample(self.paths[other])[1])
             alpha = synthesis.draw_mix_alpha()                                        # dataset.py:144
-        photos, maps = self._scale(photos, maps)
+        blend_first = self.mix_materials and self.scale_mode == "resize"       # dataset.py:52-73: mix, THEN resize
+        photos, maps = self._scale(photos, maps, resize_maps=not blend_first)
         if not self.is_linear:
             photos = utils.gamma_decode(photos)
         item = {"inputs": photos.contiguous(), "svbrdf": maps[0].contiguous()}
         if self.mix_materials:
             item["svbrdf_other"], item["mix_alpha"] = maps[1].contiguous(), alpha
+            if blend_first:
+                item["resize_to"] = self.image_size
         return item
 
 
@@ -139,7 +147,11 @@ def apply_mixing(batch_svbrdf, batch):
     if "svbrdf_other" not in batch:
         return batch_svbrdf
     other = batch["svbrdf_other"].to(batch_svbrdf.device, non_blocking=True)
-    return synthesis.mix_materials(batch_svbrdf, other, batch["mix_alpha"].reshape(-1))
+    mixed = synthesis.mix_materials(batch_svbrdf, other, batch["mix_alpha"].reshape(-1))
+    if "resize_to" in batch:            # scale_mode 'resize': the pair came centre-cropped at full resolution
+        S = int(torch.as_tensor(batch["resize_to"]).reshape(-1)[0])
+        mixed = torch.nn.functional.interpolate(mixed, size=(S, S), mode="bilinear")
+    return mixed
 
 
 class SyntheticSvbrdfDataset(torch.utils.data.Dataset):

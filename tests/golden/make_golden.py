@@ -439,6 +439,37 @@ def g12_dataset_reader():
     finally:
         random.randrange = orig
         shutil.rmtree(d)
+
+    # round 3: __getitem__ with material mixing AND scale_mode='resize' (dataset.py:52-73): the reference blends the two
+    # materials at full resolution, THEN centre-crops (landscape tiles: 40 wide x 28 high) and resizes bilinearly --
+    # the renormalisation of the blended normals does not commute with the resize, so the order is part of the contract
+    rng2 = np.random.RandomState(4321)
+    for k in range(2):
+        m = rng2.randint(0, 256, size=(28, 40 * 4, 3)).astype(np.uint8)
+        m[:, :40, 2] = np.maximum(m[:, :40, 2], 150)
+        m[:, 80:120, 1] = m[:, 80:120, 0]
+        m[:, 80:120, 2] = m[:, 80:120, 0]
+        _write_png(os.path.join(HERE, "g12_maps_wide_%d.png" % k), m)
+    d = tempfile.mkdtemp()
+    for k in range(2):
+        shutil.copy(os.path.join(HERE, "g12_maps_wide_%d.png" % k), d)
+    ds = ref_dataset.SvbrdfDataset(data_directory=d, image_size=20, scale_mode="resize", input_image_count=0,
+                                   used_input_image_count=0, use_augmentation=False, mix_materials=True)
+    ds.file_paths = sorted(ds.file_paths)
+    picked = []
+    random.randrange = spy
+    try:
+        for idx in (0, 1):
+            random.seed(13 + idx)
+            torch.manual_seed(31 + idx)
+            item = ds[idx]
+            arrays["mixresize%d__svbrdf" % idx] = item["svbrdf"].numpy()
+            arrays["mixresize%d__inputs_shape" % idx] = np.array(item["inputs"].shape, np.int64)
+            arrays["mixresize%d__partner" % idx] = np.int64(picked[-1])
+            arrays["mixresize%d__rng_after" % idx] = torch.get_rng_state().numpy()[:64].copy()
+    finally:
+        random.randrange = orig
+        shutil.rmtree(d)
     save("g12_dataset_reader.npz", **arrays)
 
 
@@ -484,6 +515,73 @@ def g13_unet_forward():
     save("g13_unet_forward.npz", **arrays)
 
 
+def _params(fn):
+    """[[name, kind, default-or-None as repr]] of a callable, `self` dropped"""
+    import inspect
+    out = []
+    for prm in inspect.signature(fn).parameters.values():
+        if prm.name == "self":
+            continue
+        out.append([prm.name, prm.kind.name, None if prm.default is inspect.Parameter.empty else repr(prm.default)])
+    return out
+
+
+def g14_api():
+    """The reference's PUBLIC SURFACE on the hot path as data: module -> name -> call signature,
+    for classes the constructor, the public methods and the public attributes of a constructed instance.  A CPU test
+    checks that the product's same-named modules expose every entry call-compatibly, so that INTEGRATION.md's
+    "swap the modules" statement cannot drift.  Out of scope (recorded by name only): RednerRenderer and
+    OrthoToPerspectiveMapping (renderers.py:106-270), the gamma/file helpers' callers."""
+    import inspect
+    in_scope = {
+        "renderers": ["LocalRenderer"],
+        "losses": ["SVBRDFL1Loss", "RenderingLoss", "MixedLoss"],
+        "environment": ["Camera", "Light", "Scene", "generate_random_scenes", "generate_specular_scenes"],
+        "utils": ["pack_svbrdf", "unpack_svbrdf", "decode_svbrdf", "encode_as_unit_interval", "decode_from_unit_interval",
+                  "gamma_encode", "gamma_decode", "generate_normalized_random_direction", "enable_deterministic_random_engine"],
+    }
+    mods = {"renderers": ref_renderers, "losses": ref_losses, "environment": ref_env, "utils": ref_utils}
+    ctor_args = {"LocalRenderer": (), "SVBRDFL1Loss": (), "Camera": ([0.0, 0.0, 1.0],),
+                 "Light": ([0.0, 0.0, 1.0], [1.0, 1.0, 1.0])}
+    api = {}
+    for mname, names in in_scope.items():
+        mod, entry = mods[mname], {}
+        for name in names:
+            obj = getattr(mod, name)
+            if inspect.isclass(obj):
+                methods = {k: _params(v) for k, v in vars(obj).items()
+                           if inspect.isfunction(v) and not k.startswith("_")}
+                if name in ("RenderingLoss", "MixedLoss"):
+                    inst = obj(ref_renderers.LocalRenderer())
+                elif name == "Scene":
+                    inst = obj(ref_env.Camera([0.0, 0.0, 1.0]), ref_env.Light([0.0, 0.0, 1.0], [1.0, 1.0, 1.0]))
+                else:
+                    inst = obj(*ctor_args[name])
+                attrs = {}
+                for k, v in vars(inst).items():
+                    if k.startswith("_") or k == "training":
+                        continue
+                    attrs[k] = v if isinstance(v, (int, float)) and not isinstance(v, bool) else type(v).__name__
+                if isinstance(inst, torch.nn.Module):
+                    for k, v in inst._modules.items():
+                        attrs[k] = type(v).__name__
+                entry[name] = {"kind": "class", "init": _params(obj.__init__), "methods": methods, "attributes": attrs,
+                               "is_nn_module": isinstance(inst, torch.nn.Module)}
+                if name == "LocalRenderer":
+                    # only `render` is called from outside renderers.py (grep of the reference: losses.py:39-40,
+                    # dataset.py:212, the notebooks); the per-term helpers are the body of render() -- rows a1-a9,
+                    # fused into the kernels -- and are recorded by name only
+                    entry[name]["methods"] = {"render": methods["render"]}
+                    entry[name]["methods_fused_into_the_kernels"] = sorted(k for k in methods if k != "render")
+            else:
+                entry[name] = {"kind": "function", "params": _params(obj)}
+        public = sorted(k for k, v in vars(mod).items() if not k.startswith("_") and getattr(v, "__module__", None) == mod.__name__)
+        api[mname] = {"in_scope": entry, "out_of_scope_names": [k for k in public if k not in names]}
+    with open(os.path.join(HERE, "g14_api.json"), "w") as f:
+        json.dump(api, f, indent=1, sort_keys=True)
+    print("wrote g14_api.json")
+
+
 def g9_kat():
     R = ref_renderers.LocalRenderer()
     out = {}
@@ -524,6 +622,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--only-dataset":        # row f4 reader + mix, added in round 2
         g12_dataset_reader()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-api":            # row b public surface, added in round 3
+        g14_api()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-unet":           # row f4 network forward, added in round 2
         g13_unet_forward()
         return
@@ -542,6 +643,7 @@ def main():
     g11_head_loss()
     g12_dataset_reader()
     g13_unet_forward()
+    g14_api()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "mworchel/svbrdf-estimation @ /root/reference (development/multiImage_pytorch)",

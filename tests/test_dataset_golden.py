@@ -80,6 +80,35 @@ def test_mixing_dataset_draws_partner_and_weight_like_the_reference(tmp_path, go
         assert np.allclose(mixed.numpy(), g["mixitem%d__svbrdf" % idx], rtol=0, atol=2e-7)
 
 
+def test_mixing_with_resize_blends_before_it_resizes_like_the_reference(tmp_path, golden):
+    """scale_mode='resize' + mix_materials: the reference blends the two materials at full resolution and centre-crops
+    / resizes afterwards (dataset.py:52-73).  The item therefore carries both materials centre-cropped and UNRESIZED
+    (landscape tiles 40 x 28 -> 28 x 28) plus `resize_to`; same partner, same weight draw, same generator state; and
+    blend -> bilinear resize of that pair (test-side restatement on the host) reproduces the reference's item."""
+    g = golden("g12_dataset_reader.npz")
+    ds = _dataset(tmp_path, ["g12_maps_wide_0.png", "g12_maps_wide_1.png"], image_size=20, scale_mode="resize",
+                  image_count=0, used_image_count=0, mix_materials=True)
+    for idx in (0, 1):
+        random.seed(13 + idx)
+        torch.manual_seed(31 + idx)
+        item = ds[idx]
+        assert np.array_equal(torch.get_rng_state().numpy()[:64], g["mixresize%d__rng_after" % idx])
+        assert item["resize_to"] == 20 and tuple(item["svbrdf"].shape) == (12, 28, 28) == tuple(item["svbrdf_other"].shape)
+        assert tuple(item["inputs"].shape) == tuple(g["mixresize%d__inputs_shape" % idx])
+        partner = int(g["mixresize%d__partner" % idx])
+        assert torch.equal(item["svbrdf_other"], ds.read_sample(ds.paths[partner])[1][:, :, 6:34])     # centre 28 of 40
+        mixed = _mix_restated(item["svbrdf"], item["svbrdf_other"], item["mix_alpha"])
+        resized = torch.nn.functional.interpolate(mixed.unsqueeze(0), size=(20, 20), mode="bilinear").squeeze(0)
+        assert np.allclose(resized.numpy(), g["mixresize%d__svbrdf" % idx], rtol=0, atol=3e-7)
+        # the other order (resize each material, then blend) is NOT what the reference returns
+        wrong = _mix_restated(*(torch.nn.functional.interpolate(m.unsqueeze(0), size=(20, 20), mode="bilinear").squeeze(0)
+                                for m in (item["svbrdf"], item["svbrdf_other"])), item["mix_alpha"])
+        assert np.abs(wrong.numpy() - g["mixresize%d__svbrdf" % idx]).max() > 1e-3
+    # the collated batch keeps the marker
+    batch = torch.utils.data.default_collate([ds[0], ds[1]])
+    assert batch["resize_to"].tolist() == [20, 20] and tuple(batch["svbrdf"].shape) == (2, 12, 28, 28)
+
+
 def _mix_restated(a, b, alpha):
     n0, n1 = a[0:3] / torch.max(torch.tensor([0.01]), a[2:3]), b[0:3] / torch.max(torch.tensor([0.01]), b[2:3])
     n = alpha * n0 + (1.0 - alpha) * n1

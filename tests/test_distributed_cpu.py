@@ -159,3 +159,31 @@ def test_train_gpus_n_spawns_n_ranks_cpu(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == 2
+
+
+def test_verify_global_batch_two_ranks_equal_one_cpu(tmp_path):
+    """train.py --verify-global-batch on the CPU plumbing configuration (gloo, stock L1 loss): two self-spawned ranks
+    with one item each against one process with both items -- contiguous shards, dropout off, DDP's averaged gradient
+    is the global-batch gradient.  (tests/test_gpu_multirank.py runs the same check on the GPU with the fused loss.)"""
+    import subprocess
+    common = ["--device", "cpu", "--loss", "l1", "--steps", "1", "--warmup", "0", "--workers", "0", "--samples", "2"]
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    for extra in (["--gpus", "1", "--batch", "2", "--verify-global-batch", one],
+                  ["--gpus", "2", "--batch", "1", "--verify-global-batch", two]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py")] + extra + common, env=_clean_env(),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.load(one), np.load(two)
+    assert int(b["world"]) == 2 and a["grad"].shape == b["grad"].shape and a["grad"].size > 79_000_000
+    assert abs(float(a["loss"]) - float(b["loss"])) <= 1e-6 * abs(float(a["loss"]))
+    assert np.abs(a["grad"] - b["grad"]).max() <= 1e-5 * np.abs(a["grad"]).max()
+
+
+def test_contiguous_shard_sampler_tiles_the_global_batches():
+    from svbrdf_estimation_amd import distributed
+    per, world, n = 3, 4, 31
+    seen = [list(distributed.ContiguousShardSampler(n, per, r, world)) for r in range(world)]
+    assert all(len(s) == 2 * per for s in seen)                       # two whole global batches of 12, the tail dropped
+    for k in range(2):
+        block = sum((s[k * per:(k + 1) * per] for s in seen), [])
+        assert block == list(range(k * 12, (k + 1) * 12))

@@ -1,0 +1,109 @@
+"""Rows (e) / (f4) on the ONE GPU a test box has: the code an N-GPU run executes, executed.
+
+The reference is single-device (development/multiImage_pytorch/main.py:33-36); the multi-GPU layout here is one
+process per GPU, batch sharded by rank, no data-path collective.  An 8-GPU node is the
+driver's to run, so these tests make every branch of that layout run on one MI355X:
+
+  * RCCL itself at world size 1 (``--force-dist``): ``init_process_group("nccl", device_id=...)``,
+    ``barrier(device_ids=...)``, the MAX all-reduce of the elapsed time on a device tensor, the global-mean
+    all-reduce, DDP's bucketed gradient all-reduce -- the branches ``bench.py`` / ``train.py`` take for N > 1;
+  * two self-spawned ranks sharing the device (``--gpus 2 --backend gloo --share-device``): rank launch, rendezvous,
+    barriers, per-rank scene streams, MAX over ranks, one JSON line -- with the HIP kernels running in both ranks;
+  * DDP over two ranks with the fused MixedLoss: the averaged gradient of a fixed global batch equals the
+    single-process gradient of the same batch.
+
+Every script is started as a FRESH child process (never a re-exec of the pytest process, which has initialised the
+GPU runtime).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra)
+    return env
+
+
+def _run(script, *argv, timeout=900, **extra_env):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, script)] + [str(a) for a in argv], env=_clean_env(**extra_env),
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, "%s %s failed (%d):\n%s" % (script, argv, r.returncode, r.stderr[-3000:])
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.strip().startswith("{") and l.strip().endswith("}")]
+    assert len(lines) == 1, "expected ONE JSON line, got %d:\n%s" % (len(lines), r.stdout[-2000:])
+    return lines[0], r.stderr
+
+
+def test_bench_rccl_process_group_of_one():
+    """bench.py's N > 1 branches over RCCL (backend "nccl"), world size 1: bench.py:init_process_group(device_id),
+    barrier(device_ids), all_reduce(MAX) of a device tensor, distributed.global_mean, all_gather, destroy"""
+    line, _ = _run("bench.py", "--gpus", 1, "--force-dist", "--steps", 40, "--warmup", 10, "--settle-ms", 20,
+                   "--no-cpu-baseline", "--no-secondary")
+    assert line["process_group"].startswith("nccl") and line["ranks_seen"] == 1 and line["n_gpus"] == 1
+    assert line["value"] > 1e4 and np.isfinite(line["loss"])
+    assert line["per_rank"]["scene_seed"] == [313] and len(line["per_rank"]["elapsed_s"]) == 1
+    assert abs(line["per_rank"]["last_loss"][0] - line["loss"]) <= 1e-6 * abs(line["loss"])
+    print("bench.py over RCCL, world 1: %.0f patches/s" % line["value"])
+
+
+def test_bench_two_self_spawned_ranks_share_the_device():
+    """`python bench.py --gpus 2` as ONE plain process (how the driver calls it): it spawns its own two ranks; with
+    --backend gloo --share-device both drive cuda:0, so the whole N-rank control flow runs with the kernels in it"""
+    line, err = _run("bench.py", "--gpus", 2, "--backend", "gloo", "--share-device", "--steps", 50, "--warmup", 10,
+                     "--settle-ms", 20, "--no-cpu-baseline", "--no-secondary")
+    assert line["launch"] == "self-spawned" and line["ranks_seen"] == 2 and line["n_gpus"] == 2
+    assert line["process_group"].startswith("gloo")
+    assert line["value"] > 1e4 and line["config"]["global_batch"] == 16
+    pr = line["per_rank"]
+    assert pr["scene_seed"] == [313, 314]                                   # per-rank scene streams
+    assert pr["last_loss"][0] != pr["last_loss"][1]                         # ... and per-rank batches
+    assert all(np.isfinite(v) for v in pr["last_loss"])
+    assert abs(0.5 * sum(pr["last_loss"]) - line["loss"]) <= 1e-6 * abs(line["loss"])     # global mean of the shard means
+    assert line["ms_per_step"] * line["steps"] * 1e-3 >= max(pr["elapsed_s"]) * (1 - 1e-9)  # MAX over ranks
+    print("bench.py, two ranks on one device: %.0f patches/s aggregate; per-rank seconds %s" % (line["value"], pr["elapsed_s"]))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "multirank_bench_share_device.json"), "w") as f:
+        json.dump(line, f, indent=1)
+
+
+def test_train_rccl_ddp_world_of_one():
+    """train.py's N > 1 branches over RCCL at world size 1: process group with device_id, DistributedDataParallel
+    around the U-Net (bucketed all-reduce of its 320 MB of gradients through RCCL), fused MixedLoss, barriers, the
+    MAX and global-mean all-reduces"""
+    line, _ = _run("train.py", "--gpus", 1, "--force-dist", "--steps", 2, "--warmup", 1, "--batch", 2, "--workers", 0,
+                   "--loss", "mixed", timeout=1500)
+    assert line["process_group"].startswith("nccl") and "DistributedDataParallel" in line["process_group"]
+    assert line["ranks_seen"] == 1 and np.isfinite(line["loss_first_quarter"]) and np.isfinite(line["loss_last_quarter"])
+
+
+def test_ddp_fused_loss_two_ranks_equal_the_global_batch(tmp_path):
+    """DDP-wrapped U-Net + fused MixedLoss on two ranks sharing the device (gloo carries the gradient all-reduce)
+    against ONE process with the whole batch: same items, same scenes per item (--verify-global-batch), so DDP's
+    average of the two shard gradients must be the global-batch gradient, and the mean of the shard losses the
+    global loss."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    common = ("--steps", 1, "--warmup", 0, "--workers", 0, "--loss", "mixed", "--samples", 4)
+    l1, _ = _run("train.py", "--gpus", 1, "--batch", 4, "--verify-global-batch", one, *common, timeout=1500)
+    l2, _ = _run("train.py", "--gpus", 2, "--backend", "gloo", "--share-device", "--batch", 2,
+                 "--verify-global-batch", two, *common, timeout=1500)
+    assert l2["ranks_seen"] == 2 and "gloo" in l2["process_group"] and l1["process_group"] is None
+    a, b = np.load(one), np.load(two)
+    assert int(a["world"]) == 1 and int(b["world"]) == 2 and a["grad"].shape == b["grad"].shape
+    assert a["grad"].size > 79_000_000                                      # every trainable parameter of the U-Net
+    assert abs(float(a["loss"]) - float(b["loss"])) <= 2e-6 * abs(float(a["loss"])), (a["loss"], b["loss"])
+    gmax = np.abs(a["grad"]).max()
+    err = np.abs(a["grad"] - b["grad"]).max()
+    print("DDP (2 ranks) vs global batch: loss %.7f / %.7f, gradient max err / max = %.2e" % (a["loss"], b["loss"], err / gmax))
+    # the convolutions' weight gradients sum over the batch in a different order (2 + 2 averaged vs 4), nothing else differs
+    assert np.isfinite(a["grad"]).all() and gmax > 0 and err <= 1e-4 * gmax

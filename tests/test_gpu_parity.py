@@ -137,6 +137,53 @@ def test_ragged_render_entry_points(dev, native, oracle):
         native.render_fwd_ragged(_t(maps, dev), _t(scenes, dev), [1, 1, 1, 1])
 
 
+def test_render_host_scene_entry_points(dev, native, oracle):
+    """svbrdf_render_{fwd,bwd}_host_scenes: the scene rows in HOST memory, carried by value in the launch's argument
+    block -- per-map tables and ONE table shared by every map (LocalRenderer.render's "one scene, B maps",
+    renderers.py:98) -- bitwise equal to the device-table entry points and within tolerance of the oracle; raw C ABI
+    call with a host pointer; the row limit."""
+    from svbrdf_estimation_amd import environment
+    B, S, H = 3, 4, 36
+    maps = synth.make_maps(41, B, H, tiled_roughness=False)
+    maps[1] = synth.make_maps(42, 1, H)[0]
+    d_maps = _t(maps, dev)
+    torch.manual_seed(14)
+    table = torch.stack([environment.scene_table(2, 2) for _ in range(B)])          # host [B,S,9]
+    cot = _t(synth.uniform01(43, (B, S, 3, H, H)) - np.float32(0.5), dev)
+    dev_out, dev_grad = native.render_fwd(d_maps, table.to(dev)), native.render_bwd(d_maps, table.to(dev), cot)
+    assert torch.equal(native.render_fwd(d_maps, table), dev_out)                   # host [B,S,9] by value
+    assert torch.equal(native.render_bwd(d_maps, table, cot), dev_grad)
+    assert_render_strict(_np(dev_out), oracle.render_fwd(maps, table.numpy()), "host-scenes fwd")
+    shared = table[0]                                                               # host [S,9]: same scenes, every map
+    expanded = shared.unsqueeze(0).expand(B, S, 9).contiguous().to(dev)
+    assert torch.equal(native.render_fwd(d_maps, shared), native.render_fwd(d_maps, expanded))
+    assert torch.equal(native.render_bwd(d_maps, shared, cot), native.render_bwd(d_maps, expanded, cot))
+    # raw C ABI, host pointer
+    lib = native._load()
+    out = torch.empty(B, S, 3, H, H, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    host_rows = np.ascontiguousarray(shared.numpy())
+    rc = lib.svbrdf_render_fwd_host_scenes(d_maps.data_ptr(), host_rows.ctypes.data_as(ctypes.c_void_p), 1,
+                                           native.xrow(dev, H).data_ptr(), out.data_ptr(), B, S, H, H, st)
+    assert rc == 0, lib.svbrdf_last_error()
+    host_rows[:] = 0                            # the rows were copied into the launch: the caller's buffer is free again
+    torch.cuda.synchronize()
+    assert torch.equal(out, native.render_fwd(d_maps, expanded))
+    # more rows than the argument block holds: the C ABI refuses, the binding uploads instead (same bits)
+    cap = native.host_scenes_max_rows()
+    p = out.data_ptr()
+    assert lib.svbrdf_render_fwd_host_scenes(p, p, 0, p, p, cap + 1, 1, 4, 4, None) == -2
+    assert lib.svbrdf_render_bwd_host_scenes(p, p, 1, p, p, p, 1, cap + 1, 4, 4, None) == -2
+    assert lib.svbrdf_render_fwd_host_scenes(p, None, 1, p, p, 1, 1, 4, 4, None) == -1
+    Sbig, Hs = cap + 7, 8
+    small = _t(synth.make_maps(44, 1, Hs), dev)
+    torch.manual_seed(15)
+    big = environment.scene_table(Sbig, 0)
+    assert torch.equal(native.render_fwd(small, big), native.render_fwd(small, big.unsqueeze(0).to(dev)))
+    with pytest.raises(ValueError):
+        native.rendering_loss(d_maps, d_maps, shared)                               # the loss takes [B,S,9] only
+
+
 def test_c_host_program_calls_the_abi(dev, golden, tmp_path):
     """a plain-C host (tests/c_host/render_host.c: gcc, the HIP runtime's C API, include/svbrdf_hip.h and nothing else)
     renders the KAT-1 case through svbrdf_render_fwd and prints the radiance; it must be the reference's value
@@ -910,6 +957,31 @@ def test_mixing_dataset_item_through_the_gpu_mix(dev, golden, tmp_path):
     for idx in (0, 1):
         ref = g["mixitem%d__svbrdf" % idx]
         assert np.array_equal(mixed[idx, 3:], ref[3:]) and np.abs(mixed[idx, :3] - ref[:3]).max() <= 2.4e-7
+
+
+def test_mixing_dataset_with_resize_through_the_gpu(dev, golden, tmp_path):
+    """scale_mode='resize' + mix_materials end to end: dataloader item (both materials centre-cropped, unresized) ->
+    apply_mixing = K4 blend at full resolution, THEN bilinear resize on the device -- the reference's order
+    (dataset.py:52-73) -- against the reference's __getitem__ output (g12 mixresize*)"""
+    import random
+    import shutil
+    from svbrdf_estimation_amd.training import data
+    g = golden("g12_dataset_reader.npz")
+    for k in range(2):
+        shutil.copy(os.path.join(os.path.dirname(__file__), "golden", "g12_maps_wide_%d.png" % k), str(tmp_path))
+    ds = data.TiledPngDataset(str(tmp_path), image_size=20, image_count=0, used_image_count=0, scale_mode="resize",
+                              mix_materials=True)
+    items = []
+    for idx in (0, 1):
+        random.seed(13 + idx)
+        torch.manual_seed(31 + idx)
+        items.append(ds[idx])
+    batch = torch.utils.data.default_collate(items)
+    mixed = _np(data.apply_mixing(batch["svbrdf"].to(dev), batch))
+    assert mixed.shape == (2, 12, 20, 20)
+    for idx in (0, 1):
+        err = np.abs(mixed[idx] - g["mixresize%d__svbrdf" % idx]).max()
+        assert err <= 5e-7, (idx, err)
 
 
 @pytest.mark.parametrize("tag", ["single", "multi"])

@@ -3,6 +3,7 @@ behaviour) and the C ABI's load/export contract.  No kernel is launched here."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -291,3 +292,111 @@ def test_header_is_valid_c_and_the_c_host_builds(tmp_path):
                            "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_host", "render_host.c"),
                            "-o", str(tmp_path / "render_host"), "-L" + lib, "-lsvbrdf_hip", "-L/opt/rocm/lib", "-lamdhip64",
                            "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+
+
+# ---------------------------------------------------------------- row b: the reference's public surface, pinned
+def _sig_params(fn):
+    import inspect
+    return [p for p in inspect.signature(fn).parameters.values() if p.name != "self"]
+
+
+def _assert_call_compatible(ref_params, fn, what):
+    """every call the reference's signature accepts must bind to `fn` the same way: same parameter names in the same
+    positions, the same ones optional with equal defaults; `fn` may only ADD optional parameters after them"""
+    import inspect
+    got = _sig_params(fn)
+    if ref_params and ref_params[0][1] == "VAR_POSITIONAL":            # reference: def __init__(self, *args, **kwargs) of
+        return                                                         # object / nn.Module -- called without arguments
+    assert len(got) >= len(ref_params), "%s: %d parameters, the reference has %d" % (what, len(got), len(ref_params))
+    for (name, kind, default), p in zip(ref_params, got):
+        assert p.name == name and p.kind.name == kind, "%s: parameter %r (%s) vs reference %r (%s)" % (what, p.name, p.kind.name, name, kind)
+        if default is None:
+            assert p.default is inspect.Parameter.empty, "%s: %s must stay required" % (what, name)
+        else:
+            assert repr(p.default) == default, "%s: default of %s is %r, reference %s" % (what, name, p.default, default)
+    for p in got[len(ref_params):]:
+        assert p.default is not inspect.Parameter.empty or p.kind.name in ("VAR_POSITIONAL", "VAR_KEYWORD"), \
+            "%s: extra parameter %s has no default" % (what, p.name)
+
+
+def test_public_surface_matches_the_reference():
+    """tests/golden/g14_api.json = the reference's hot-path modules as data (names, call signatures, public attributes
+    of constructed objects; make_golden.py g14_api).  INTEGRATION.md section 1 swaps the reference's flat modules for
+    this package's same-named ones; this pins that every name a caller can reach through them exists here and binds
+    the same calls."""
+    import importlib
+    import inspect
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "g14_api.json")) as f:
+        api = json.load(f)
+    assert set(api) == {"renderers", "losses", "environment", "utils"}
+    from svbrdf_estimation_amd import environment, renderers
+    for mname, spec in api.items():
+        mod = importlib.import_module("svbrdf_estimation_amd." + mname)
+        for name, ref in spec["in_scope"].items():
+            assert hasattr(mod, name), "svbrdf_estimation_amd.%s lacks %s" % (mname, name)
+            obj = getattr(mod, name)
+            what = "%s.%s" % (mname, name)
+            if ref["kind"] == "function":
+                _assert_call_compatible(ref["params"], obj, what)
+                continue
+            assert inspect.isclass(obj), what
+            _assert_call_compatible(ref["init"], obj.__init__, what + ".__init__")
+            for meth, params in ref["methods"].items():
+                assert callable(getattr(obj, meth, None)), "%s lacks method %s" % (what, meth)
+                _assert_call_compatible(params, getattr(obj, meth), "%s.%s" % (what, meth))
+            if name in ("RenderingLoss", "MixedLoss"):
+                inst = obj(renderers.LocalRenderer())
+            elif name == "Scene":
+                inst = obj(environment.Camera([0.0, 0.0, 1.0]), environment.Light([0.0, 0.0, 1.0], [1.0, 1.0, 1.0]))
+            elif name == "Camera":
+                inst = obj([0.0, 0.0, 1.0])
+            elif name == "Light":
+                inst = obj([0.0, 0.0, 1.0], [1.0, 1.0, 1.0])
+            else:
+                inst = obj()
+            assert isinstance(inst, torch.nn.Module) == ref["is_nn_module"], what
+            for attr, val in ref["attributes"].items():
+                assert hasattr(inst, attr), "%s instance lacks attribute %s" % (what, attr)
+                if isinstance(val, (int, float)):
+                    assert getattr(inst, attr) == val, "%s.%s = %r, reference %r" % (what, attr, getattr(inst, attr), val)
+                else:
+                    assert type(getattr(inst, attr)).__name__ == val, "%s.%s is a %s, reference %s" % (
+                        what, attr, type(getattr(inst, attr)).__name__, val)
+    # what is deliberately absent is exactly what DESIGN.md lists as out of scope
+    assert set(api["renderers"]["out_of_scope_names"]) == {"OrthoToPerspectiveMapping", "RednerRenderer", "dot_product", "normalize"}
+
+
+_REFERENCE = "/root/reference/development/multiImage_pytorch"
+
+
+@pytest.mark.skipif(not os.path.isdir(_REFERENCE), reason="needs the reference checkout (build container only)")
+def test_install_patches_the_reference_modules_in_a_fresh_interpreter():
+    """INTEGRATION.md section 1 against the REAL reference, in a child interpreter (the reference's flat module names
+    would shadow this suite's): after ``svbrdf_estimation_amd.install()`` the reference's own import lines
+    (main.py:8,12; dataset.py:7,206) resolve to this engine's classes, RednerRenderer and the rest stay the
+    reference's, and ``MixedLoss(LocalRenderer())`` (main.py:82-89) is wired to the fused kernel."""
+    import subprocess
+    code = """
+import sys, types
+sys.dont_write_bytecode = True
+sys.modules.setdefault("cv2", types.ModuleType("cv2")); sys.modules.setdefault("pyredner", types.ModuleType("pyredner"))
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import svbrdf_estimation_amd as amd
+replaced = amd.install()
+from losses import MixedLoss                          # main.py:8
+from renderers import LocalRenderer, RednerRenderer   # main.py:12
+import renderers, losses, environment, utils
+assert LocalRenderer is amd.renderers.LocalRenderer and MixedLoss is amd.losses.MixedLoss
+assert losses.RenderingLoss is amd.losses.RenderingLoss and renderers.LocalRenderer is LocalRenderer
+assert RednerRenderer.__module__ == "renderers" and environment.__file__.startswith(%r) and utils.__file__.startswith(%r)
+assert sorted(replaced) == ["losses.MixedLoss", "losses.RenderingLoss", "losses.SVBRDFL1Loss", "renderers.LocalRenderer"]
+assert all(v is not None and v.__module__ in ("renderers", "losses") for v in replaced.values())
+loss_function = MixedLoss(LocalRenderer())            # main.py:82-89
+assert loss_function.rendering_loss.uses_fused_kernel() and loss_function.l1_weight == 0.1
+import dataset                                        # dataset.py:7 `import renderers` -> :206 renderers.LocalRenderer()
+assert dataset.renderers.LocalRenderer is LocalRenderer
+print("INSTALL-OK")
+""" % (_REFERENCE, ROOT, _REFERENCE, _REFERENCE)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "INSTALL-OK" in r.stdout, r.stderr[-3000:]

@@ -28,7 +28,7 @@ HEADLINE = "k_rendering_loss_inlILb1ELb0ELb0"
 # budgets: measured values of the shipped build + a small margin (tools/isa_stats.py prints the current ones).
 # The scene loops hold TWO renders per trip (geometry ping-pong), so the counts are per two renders.
 RENDERS_PER_TRIP = 2
-TIED_LOOP_VALU_MAX = 650             # 640 = 320 per render (round 1: 336)
+TIED_LOOP_VALU_MAX = 660             # headline 646 = 323 per render (round 1: 336; round 2: 320, +3 since the L1 sign of an exact-zero log is 0); device-table MixedLoss 656
 TIED_LOOP_TRANS = 26                 # 13 per render
 UNTIED_LOOP_VALU_MAX = 880           # RenderingLoss kernel: 864 (three lobes, channel by channel)
 UNTIED_LOOP_TRANS = 54               # 27 per render

@@ -66,10 +66,31 @@ def parse_args(argv=None):
     ap.add_argument("--resume", default=None,
                     help="checkpoint to start from: one written by --save, or a checkpoint.tar of the reference "
                          "(persistence.py:52-69; model weights only)")
-    ap.add_argument("--autotune", action="store_true",
-                    help="let MIOpen pick the fastest convolution algorithms (cudnn.benchmark) instead of the "
-                         "reference's deterministic setting (utils.py:11-12)")
+    ap.add_argument("--conv-mode", choices=("reference", "fast", "autotune"), default="reference",
+                    help="how stock PyTorch-ROCm picks the U-Net's MIOpen convolution algorithms.  reference: "
+                         "cudnn.deterministic=True, benchmark=False as utils.py:11-12 sets them -- on ROCm that pins every "
+                         "convolution to MIOpen's im2col+GEMM algorithm, one GEMM per image (DESIGN.md section 10); fast: "
+                         "deterministic=False, benchmark=False -- MIOpen's immediate-mode heuristic choice, no search; "
+                         "autotune: benchmark=True -- MIOpen's find step times the candidates at the first call of every "
+                         "shape")
+    ap.add_argument("--autotune", action="store_true", help="same as --conv-mode autotune")
     ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights for the U-Net")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank uses cuda:0 (with --backend gloo: the N-rank control flow, DDP included, on a box with "
+                         "fewer GPUs than ranks; tests/test_gpu_multirank.py)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with one rank: still create the process group (world size 1), wrap the network in DDP and take "
+                         "every multi-rank branch, so that the RCCL code an N-GPU run executes runs on a one-GPU box")
+    ap.add_argument("--verify-global-batch", default=None, metavar="NPZ",
+                    help="verification run: makes an N-rank run and a one-rank run of the same GLOBAL batch comparable -- "
+                         "contiguous unshuffled shards, dropout off, the network's input photo taken from the diffuse map, "
+                         "and ONE scene stream (every rank seeds alike and skips the draws that belong to the other ranks' "
+                         "items) -- and writes rank 0's gradient after the first backward (DDP-averaged) and the global "
+                         "loss to this file")
+    ap.add_argument("--phase-times", action="store_true",
+                    help="bracket the phases of every timed step (dataloader wait on the host clock; upload + input "
+                         "synthesis, network forward, loss, backward, optimizer with HIP events) and report their means: "
+                         "costs one device synchronisation per step, so `value` of such a run is not a throughput figure")
     return ap.parse_args(argv)
 
 
@@ -87,35 +108,67 @@ def run(args):
     on_gpu = args.device == "cuda"
     if on_gpu:
         assert torch.cuda.is_available(), "no ROCm device visible"
+        if args.share_device:
+            local_rank = 0
+        elif torch.cuda.device_count() < world:
+            raise SystemExit("%d ranks but only %d device(s) visible" % (world, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     else:
         if args.loss != "l1":
             raise SystemExit("the rendering loss has no CPU path; --device cpu only supports --loss l1 (plumbing tests)")
+        if args.mix_materials:
+            raise SystemExit("--mix-materials blends on the GPU (kernel K4); there is no CPU path for it")
         dev = torch.device("cpu")
-    if world > 1:
+    grouped = world > 1 or args.force_dist
+    backend = (args.backend or ("nccl" if on_gpu else "gloo")) if grouped else None
+    nccl = backend == "nccl"
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = args.backend or ("nccl" if on_gpu else "gloo")
-        dist.init_process_group(backend=backend, **({"device_id": dev} if on_gpu else {}))
+        if world == 1:                          # --force-dist without a launcher: a rendezvous of one
+            from svbrdf_estimation_amd import launch
+            os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(backend=backend, **({"device_id": dev} if nccl else {}))
 
-    utils.enable_deterministic_random_engine(distributed.rank_seed(args.seed, rank))   # per-rank scene RNG
+    def barrier():
+        if nccl:
+            dist.barrier(device_ids=[local_rank])
+        else:
+            dist.barrier()
+
+    verify = args.verify_global_batch
+    # per-rank scene RNG -- or, for --verify-global-batch, one stream shared by all ranks (each skips the others' draws)
+    utils.enable_deterministic_random_engine(args.seed if verify else distributed.rank_seed(args.seed, rank))
     decode = not args.fused_head
     if args.model == "multi":
         net = models.MultiViewModel(use_coords=not args.no_coords, decode=decode)
     else:
         net = models.SingleViewModel(use_coords=not args.no_coords, decode=decode)
     # identical initial weights on every rank: DDP broadcasts rank 0's parameters at construction
-    if args.autotune:
+    conv_mode = "autotune" if args.autotune else args.conv_mode
+    if conv_mode != "reference":                # enable_deterministic_random_engine set the reference's flags above
         torch.backends.cudnn.deterministic = False
-        torch.backends.cudnn.benchmark = True
+        torch.backends.cudnn.benchmark = conv_mode == "autotune"
+    steps_done = 0
     if args.resume:
         ck = torch.load(args.resume, map_location="cpu", weights_only=False)
-        net.load_state_dict(models.convert_reference_state_dict(ck["model_state_dict"]))
+        state = ck["model_state_dict"]
+        own = set(net.state_dict().keys())
+        # a checkpoint in the reference's parameter names (what --save writes, and what the reference writes), or one in
+        # this package's own names (written by --save before it switched to the reference's layout)
+        net.load_state_dict(state if set(state.keys()) <= own else models.convert_reference_state_dict(state))
+        steps_done = int(ck.get("steps", 0))
     net = net.to(dev).train()
+    if verify:
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
     if args.channels_last:
         net = net.to(memory_format=torch.channels_last)
     model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank] if on_gpu else None) \
-        if world > 1 else net
+        if grouped else net
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
     if args.resume and "optimizer_state_dict_amd" in ck:
         optimizer.load_state_dict(ck["optimizer_state_dict_amd"])
@@ -139,8 +192,11 @@ def run(args):
                                        used_image_count=args.views, is_linear=args.linear_input,
                                        scale_mode=args.scale_mode, random_crop=args.random_crop,
                                        mix_materials=args.mix_materials)
-    sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True,
-                                                              seed=args.seed, drop_last=True) if world > 1 else None
+    if verify:
+        sampler = distributed.ContiguousShardSampler(len(dataset), args.batch, rank, world)
+    else:
+        sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True,
+                                                                  seed=args.seed, drop_last=True) if world > 1 else None
     loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch, sampler=sampler, shuffle=sampler is None,
                                          num_workers=args.workers, pin_memory=on_gpu, drop_last=True,
                                          persistent_workers=args.workers > 0)
@@ -148,55 +204,101 @@ def run(args):
     def batches():
         epoch = 0
         while True:
-            if sampler is not None:
+            if sampler is not None and hasattr(sampler, "set_epoch"):
                 sampler.set_epoch(epoch)
             for b in loader:
                 yield b
             epoch += 1
+
+    phases = ("data_wait", "upload_synthesis", "forward", "loss", "backward", "optimizer")
+    phase_ms = {k: [] for k in phases}
+    timing = args.phase_times and on_gpu
+
+    def mark():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
 
     losses_seen, t0, it = [], None, batches()
     for step in range(total_steps):
         if step == args.warmup:
             if on_gpu:
                 torch.cuda.synchronize(dev)
-            if world > 1:
-                dist.barrier()
+            if grouped:
+                barrier()
             t0 = time.perf_counter()
+        t_wait = time.perf_counter()
         batch = next(it)
+        t_wait = time.perf_counter() - t_wait
+        marks = [mark()] if timing else None
         svbrdf = batch["svbrdf"].to(dev, non_blocking=True)
         stored = batch["inputs"].to(dev, non_blocking=True)
-        if on_gpu:
+        if on_gpu and not verify:
             svbrdf = data.apply_mixing(svbrdf, batch)                            # K4: material mixing, whole batch
             photos = data.complete_inputs(stored, svbrdf, args.views)           # K1: missing photos, whole batch
         else:                                                                    # CPU plumbing runs: constant photos
             photos = torch.cat((stored, svbrdf[:, None, 3:6].expand(-1, max(args.views - stored.shape[1], 0), -1, -1, -1)), 1)
         net_in = photos if args.model == "multi" else photos[:, 0]
         optimizer.zero_grad(set_to_none=True)
+        if timing:
+            marks.append(mark())
         out = model(net_in)
+        if timing:
+            marks.append(mark())
+        if verify and args.loss != "l1":                                         # the scenes of the lower ranks' items
+            if rank > 0:
+                loss_fn.rendering_loss.sample_scene_table(rank * args.batch)
         loss = loss_fn(out, svbrdf)
+        if verify and args.loss != "l1":                                         # ... and of the higher ranks' items
+            if rank < world - 1:
+                loss_fn.rendering_loss.sample_scene_table((world - 1 - rank) * args.batch)
+        if timing:
+            marks.append(mark())
         loss.backward()
+        if verify and step == 0:
+            g_loss = distributed.global_mean(loss.detach() if (nccl or not grouped) else loss.detach().cpu()).item()
+            if rank == 0:
+                import numpy as np
+                flat = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.grad is not None])
+                np.savez(verify, grad=flat.cpu().numpy(), loss=np.float64(g_loss), world=world, per_rank_batch=args.batch)
+        if timing:
+            marks.append(mark())
         optimizer.step()
         losses_seen.append(loss.detach())
+        if timing:
+            marks.append(mark())
+            torch.cuda.synchronize(dev)
+            if step >= args.warmup:
+                phase_ms["data_wait"].append(1e3 * t_wait)
+                for name, a, b in zip(phases[1:], marks[:-1], marks[1:]):
+                    phase_ms[name].append(a.elapsed_time(b))
     if on_gpu:
         torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
+    if grouped:
+        barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if grouped:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     vals = torch.stack(losses_seen).float()
+    if grouped and not nccl:
+        vals = vals.cpu()
     first, last = vals[: max(1, len(vals) // 4)].mean(), vals[-max(1, len(vals) // 4):].mean()
     first, last = distributed.global_mean(first).item(), distributed.global_mean(last).item()
     result = {"metric": "end-to-end training patches/s (U-Net + %s loss)" % args.loss,
               "value": world * args.batch * args.steps / elapsed, "unit": "patches/s", "n_gpus": world,
-              "ranks_seen": dist.get_world_size() if world > 1 else 1,
+              "ranks_seen": dist.get_world_size() if grouped else 1,
+              "process_group": ("%s, world size %d, DistributedDataParallel" % (backend, dist.get_world_size())) if grouped else None,
               "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps, "warmup": args.warmup,
               "loss_first_quarter": first, "loss_last_quarter": last,
               "config": {"model": args.model, "views": args.views, "size": args.size, "per_gpu_batch": args.batch,
                          "scenes": args.random_scenes + args.specular_scenes, "fused_head": bool(args.fused_head),
-                         "data": args.data if args.data == "synthetic" else "tiled-png"}}
+                         "data": args.data if args.data == "synthetic" else "tiled-png",
+                         "workers": args.workers, "conv_mode": conv_mode, "channels_last": bool(args.channels_last)}}
+    if timing:
+        result["phase_ms_mean"] = {k: sum(v) / max(1, len(v)) for k, v in phase_ms.items()}
+        result["phase_note"] = "per-step means over the timed steps; one device synchronisation per step (not a throughput run)"
     if rank == 0:
         if args.save:
             # the reference's checkpoint.tar layout (persistence.py:52-69) with the REFERENCE's parameter names, so that
@@ -205,9 +307,9 @@ def run(args):
             # under its own key instead of one the reference would load into the wrong slots.
             torch.save({"model_type": args.model, "use_coords": not args.no_coords, "epoch": 0,
                         "model_state_dict": models.convert_to_reference_state_dict(net.state_dict()),
-                        "optimizer_state_dict_amd": optimizer.state_dict(), "steps": total_steps}, args.save)
+                        "optimizer_state_dict_amd": optimizer.state_dict(), "steps": steps_done + total_steps}, args.save)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
     return result
 
