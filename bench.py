@@ -3,15 +3,21 @@
 
 One "step" = one pass of the hot path over one batch of synthetic input:
 ``loss = RenderingLoss(LocalRenderer())(input, target); loss.backward()`` -- scene
-sampling on the host (reference RNG order), one H2D copy of the [B,S,9] scene table, the
-fused K3 kernel (both renderings, log/L1, analytic backward, in-kernel loss finalise) and the
-no-op-when-1 device-side gradient scale of the autograd wrapper.
-Inputs are resident in HBM before the timed region starts.
+sampling on the host (reference RNG order), the [B,S,9] scene table handed to the launch by value,
+the fused K3 kernel (both renderings, log/L1, analytic backward, in-kernel loss finalise) and the
+gradient hand-over to ``input.grad``.  Inputs are resident in HBM before the timed region starts.
 
 Workload = BASELINE.json configs[1]: synthetic 256x256 SVBRDF maps, 9 light/view samples
-(3 random + 6 specular), per-GPU batch 8, fp32.  N > 1: one process per GPU (torchrun),
-batch sharded by rank, NO data-path collective (the path is embarrassingly parallel);
-the only collectives are the barrier and the MAX over ranks of the elapsed time.
+(3 random + 6 specular), per-GPU batch 8, fp32.  N > 1: one process per GPU (torchrun, or
+self-spawned: ``python bench.py --gpus N``), batch sharded by rank, NO data-path collective (the
+path is embarrassingly parallel); the only collectives are the barrier, the MAX over ranks of the
+elapsed time and two small reporting reductions.
+
+`value` is measured with EVERY STEP ON ONE STREAM (the default, --streams 1): what a training loop,
+whose steps the optimizer serialises, gets from the loss.  The same run also times independent steps
+alternating on two HIP streams (one step's kernel fills the ramp and tail of the other's) and reports
+that beside the headline as `value_two_streams_overlapped` / `two_streams_overlapped` -- a property
+of a bench loop over independent batches, not of one training loop.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
 (HBM-bound accounting of the dominant kernel k_rendering_loss: algorithmic bytes

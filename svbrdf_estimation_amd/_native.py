@@ -409,9 +409,15 @@ def clock_probe(out, ticks=300000, stream=None):
     return out
 
 
+_host_rows = None
+
+
 def host_scenes_max_rows():
     """largest B*S the *_host_scenes entry points take (the table rides in the launch's kernel-argument block)"""
-    return int(_load().svbrdf_host_scenes_max_rows())
+    global _host_rows
+    if _host_rows is None:
+        _host_rows = int(_load().svbrdf_host_scenes_max_rows())
+    return _host_rows
 
 
 def scale_inplace_(data, scale):

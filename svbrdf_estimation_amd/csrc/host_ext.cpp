@@ -14,6 +14,7 @@
 // Built by __graft_entry__.build() with torch.utils.cpp_extension (plain C++ extension).
 
 #include <torch/extension.h>
+#include <torch/csrc/autograd/graph_task.h>
 #include <torch/csrc/autograd/anomaly_mode.h>
 #include <torch/csrc/autograd/functions/utils.h>
 #include <ATen/CPUGeneratorImpl.h>
@@ -277,31 +278,38 @@ struct FusedLossBackward : public torch::autograd::Node {
 
     torch::autograd::variable_list apply(torch::autograd::variable_list &&grads) override
     {
-        TORCH_CHECK(!done, "the fused rendering loss was already back-propagated; its gradient buffer is scaled in place, "
-                           "so call forward again instead of retain_graph");
-        done = true;
+        TORCH_CHECK(!done, "Trying to backward through the fused rendering loss a second time: its gradient buffers were "
+                           "handed to the first backward.  Specify retain_graph=True for that call (the buffers then stay "
+                           "with the graph and each backward receives a scaled copy), as with any autograd graph "
+                           "(losses.py:29-52 is plain autograd in the reference).");
         // the upstream gradient of the scalar loss, as a one-element fp32 device buffer (loss.backward() hands over
         // exactly that: no ops needed)
         const at::Tensor &g0 = grads[0];
         TORCH_CHECK(g0.defined(), "fused rendering loss: undefined upstream gradient");
         const auto scale = (g0.scalar_type() == at::kFloat && g0.numel() == 1 && g0.is_contiguous())
                                ? g0 : g0.detach().to(at::kFloat).reshape({1});
-        // The buffers are MOVED out of the node: AccumulateGrad adopts a gradient it holds the only
-        // reference to and clones it otherwise (measured: a 25 MB device copy, 7.4 us, per step).
+        // retain_graph=True: the node must stay usable, so the kernel's buffers stay here and the caller gets a scaled
+        // COPY (one extra pass over the gradient).  Otherwise -- the training loop -- the buffers are MOVED out and scaled
+        // in place: AccumulateGrad adopts a gradient it holds the only reference to and clones it otherwise (measured:
+        // a 25 MB device copy, 7.4 us, per step).
+        const bool keep = torch::autograd::get_current_graph_task_keep_graph();
+        if (!keep) done = true;
         torch::autograd::variable_list out(2);
+        at::AutoDispatchBelowADInplaceOrView below_autograd;
         if (has_in) {
-            check(g_abi.scale(grad_in.data_ptr<float>(), scale.data_ptr<float>(), (size_t)grad_in.numel(), stream), "svbrdf_scale_inplace");
-            out[0] = std::move(grad_in);
+            out[0] = keep ? grad_in.clone() : std::move(grad_in);
+            check(g_abi.scale(out[0].data_ptr<float>(), scale.data_ptr<float>(), (size_t)out[0].numel(), stream), "svbrdf_scale_inplace");
         }
         if (has_tg) {
-            check(g_abi.scale(grad_tg.data_ptr<float>(), scale.data_ptr<float>(), (size_t)grad_tg.numel(), stream), "svbrdf_scale_inplace");
-            out[1] = std::move(grad_tg);
+            out[1] = keep ? grad_tg.clone() : std::move(grad_tg);
+            check(g_abi.scale(out[1].data_ptr<float>(), scale.data_ptr<float>(), (size_t)out[1].numel(), stream), "svbrdf_scale_inplace");
         }
         return out;
     }
 
     void release_variables() override
     {
+        done = true;
         grad_in.reset();
         grad_tg.reset();
     }

@@ -50,18 +50,32 @@ class _FusedRenderingLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_loss):
-        if ctx.grads is None:
-            raise RuntimeError("the fused rendering loss was already back-propagated; its gradient buffer is "
-                               "scaled in place, so call forward again instead of retain_graph")
         grad_in, grad_tg = ctx.grads
-        ctx.grads = None
-        # chain rule through the scalar loss: scaled on the device, skipped when the upstream
-        # gradient is exactly 1 (loss.backward(), MixedLoss) -- no host sync either way
+        # chain rule through the scalar loss on the device (no host sync).  This is the FALLBACK host path (the native
+        # extension is the default: csrc/host_ext.cpp moves the buffer out and scales it in place unless
+        # retain_graph=True); here the buffers stay with the graph and every backward gets a scaled copy, so a second
+        # backward(retain_graph=True) works as it does through the reference's plain-autograd loss (losses.py:29-52).
         scale = grad_loss.detach().to(torch.float32).reshape(1)
+        outs = []
         for g in (grad_in, grad_tg):
-            if g is not None:
-                _native.scale_inplace_(g, scale)
-        return grad_in, grad_tg, None, None, None, None, None
+            outs.append(None if g is None else _native.scale_inplace_(g.clone(), scale))
+        return outs[0], outs[1], None, None, None, None, None
+
+
+def _fast_backward_enabled():
+    """The engine-free ``loss.backward()`` of a leaf input (``_FusedLossTensor``) reads autograd internals that move
+    between torch releases (the leaf's gradient accumulator and its hook lists), so it is only taken on torch versions
+    it has been tested against; everywhere else ``loss.backward()`` is the autograd engine's.  SVBRDF_FAST_BACKWARD=0/1
+    overrides."""
+    import os
+    env = os.environ.get("SVBRDF_FAST_BACKWARD")
+    if env is not None:
+        return env not in ("0", "")
+    return ".".join(torch.__version__.split("+")[0].split(".")[:2]) in _FAST_BACKWARD_TESTED_TORCH
+
+
+_FAST_BACKWARD_TESTED_TORCH = ("2.10",)
+_FAST_BACKWARD = _fast_backward_enabled()
 
 
 class _FusedLossTensor(torch.Tensor):
@@ -77,7 +91,7 @@ class _FusedLossTensor(torch.Tensor):
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         src = self.__dict__.pop("_svbrdf_src", None)
-        if src is not None and gradient is None and not retain_graph and not create_graph and inputs is None:
+        if src is not None and _FAST_BACKWARD and gradient is None and not retain_graph and not create_graph and inputs is None:
             inner, leaf, ext = src
             if ext.fast_backward(inner, leaf, _native._raw_stream(leaf.device)):
                 return None

@@ -175,6 +175,19 @@ class SyntheticSvbrdfDataset(torch.utils.data.Dataset):
         return {"inputs": torch.zeros(0, 3, H, H), "svbrdf": torch.cat((n, d, r, s), dim=0).contiguous()}
 
 
+def synthetic_svbrdf_batch(batch, image_size, device, generator):
+    """[B,12,H,W] random SVBRDF maps with SyntheticSvbrdfDataset's statistics, drawn on `device` with `generator`
+    (train.py --data synthetic: no dataloader in the way of the step rate)"""
+    H = image_size
+    n = torch.randn(batch, 3, H, H, device=device, generator=generator) * 0.3
+    n[:, 2] = 1.0 + n[:, 2].abs()
+    n = n / n.norm(dim=1, keepdim=True)
+    d = torch.rand(batch, 3, H, H, device=device, generator=generator)
+    r = torch.rand(batch, 1, H, H, device=device, generator=generator).expand(batch, 3, H, H)
+    s = torch.rand(batch, 3, H, H, device=device, generator=generator)
+    return torch.cat((n, d, r, s), dim=1)
+
+
 def complete_inputs(batch_inputs, batch_svbrdf, used_image_count, use_augmentation=True, noise="device"):
     """device tensors: [B,n,3,H,W] stored photos (n may be 0) + [B,12,H,W] maps -> [B,used,3,H,W], the missing
     ones rendered by one launch of K1 for the whole batch (dataset.py:94-98 did this per sample on the CPU)."""

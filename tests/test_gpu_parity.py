@@ -620,9 +620,13 @@ def test_render_inputs_matches_reference_dataloader(dev, oracle, golden):
             assert np.array_equal(torch.get_rng_state().numpy()[:64], g[k + "__rng_after"]), k
             ref = g[k + "__out"]
             err = np.abs(_np(out) - ref)
-            # photos are clamped to [0,1]; a highlight pixel carries the reference's own sqrt noise
-            # (DESIGN.md 4.2), so: 99.9 % within 1e-5 rel + 2e-6, every pixel within 3e-5 absolute
-            assert (err <= 1e-5 * np.abs(ref) + 2e-6).mean() >= 0.999, (k, err.max())
+            # photos are clamped to [0,1]; a highlight pixel carries the reference's own sqrt noise, so:
+            # at most MAX_WIDENED_RENDER pixels of a case (counted, printed) outside 1e-5 rel + 2e-6, every pixel
+            # within 3e-5 absolute
+            from tolerances import MAX_WIDENED_RENDER, _record
+            outside = int((err > 1e-5 * np.abs(ref) + 2e-6).sum())
+            _record("render_inputs " + k, "outside 1e-5 rel + 2e-6", outside, err.size, min(MAX_WIDENED_RENDER, 8 * n))
+            assert outside <= min(MAX_WIDENED_RENDER, 8 * n), (k, outside, err.max())
             assert err.max() <= 3e-5, (k, err.max())
             assert out.min().item() >= 0.0 and out.max().item() <= 1.0
     # batched: B samples x count photos in one launch; device noise is statistically right
@@ -676,12 +680,46 @@ def test_host_extension_and_ctypes_paths_are_bitwise_identical(dev, golden):
     native_tab = _hostext.module().sample_scene_table(2, 3, 6)
     assert torch.equal(native_tab, per_item)
     np.testing.assert_allclose(native_tab.numpy(), g5["seed_99_two_items"], rtol=3e-7, atol=1e-7)
-    # double backward is refused loudly (the gradient buffer is scaled in place)
-    x = _t(g["input"], dev).requires_grad_(True)
-    loss = losses.RenderingLoss(renderers.LocalRenderer())(x, _t(g["target"], dev))
-    loss.backward(retain_graph=True)
-    with pytest.raises(RuntimeError):
-        loss.backward()
+
+
+def test_retain_graph_allows_a_second_backward_like_plain_autograd(dev, golden):
+    """losses.py:29-52 is plain autograd in the reference, so ``loss.backward(retain_graph=True)`` followed by another
+    backward works there.  Here the kernel's gradient buffer is normally MOVED to the caller and scaled in place; with
+    retain_graph=True it stays with the graph and each backward receives a scaled copy.  Both host paths; a backward
+    after a non-retaining one still fails loudly, as with any freed graph."""
+    from svbrdf_estimation_amd import _hostext, environment, losses, renderers
+    g = golden("g3_loss_48.npz")
+    d_tg = _t(g["target"], dev)
+    fn = losses.RenderingLoss(renderers.LocalRenderer())
+
+    def via_module(x):
+        torch.manual_seed(3)
+        return fn(x, d_tg)
+
+    def via_ctypes(x):
+        torch.manual_seed(3)
+        return losses._FusedRenderingLoss.apply(x, d_tg, fn.sample_scene_table(x.shape[0]), 0.1)
+
+    assert _hostext.module() is not None
+    for make in (via_module, via_ctypes):
+        x = _t(g["input"], dev).requires_grad_(True)
+        make(x).backward()
+        once = x.grad.clone()
+        x = _t(g["input"], dev).requires_grad_(True)
+        loss = make(x)
+        loss.backward(retain_graph=True)
+        assert torch.equal(x.grad, once)
+        loss.backward(torch.tensor(0.5, device=dev), retain_graph=True)        # a scaled copy, the buffer is untouched
+        assert torch.equal(x.grad, once + 0.5 * once)
+        loss.backward()                                                          # last one: may consume the buffer
+        assert torch.equal(x.grad, (once + 0.5 * once) + once)
+        with pytest.raises(RuntimeError):
+            loss.backward()
+        w = torch.full((1,), 2.0, device=dev, requires_grad=True)               # non-leaf input (the training case)
+        loss = make(_t(g["input"], dev) * w)
+        (g1,) = torch.autograd.grad(loss, w, retain_graph=True)
+        (g2,) = torch.autograd.grad(loss, w)
+        assert torch.equal(g1, g2) and torch.isfinite(g1).all()
 
 
 def test_host_scene_table_rides_in_the_kernel_arguments(dev, native, golden):

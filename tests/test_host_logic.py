@@ -275,7 +275,10 @@ def test_header_is_valid_c_and_the_c_host_builds(tmp_path):
     """include/svbrdf_hip.h must be consumable by a C compiler (the boundary is a C ABI): compiled alone as strict
     C99, every declared function referenced; and the plain-C host program of the GPU suite must build and link"""
     import re
+    import shutil
     import subprocess
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include/hip"):
+        pytest.skip("toolchain test: needs gcc and the ROCm headers under /opt/rocm/include")
     header = os.path.join(ROOT, "include", "svbrdf_hip.h")
     names = sorted(set(re.findall(r"\b(svbrdf_\w+)\s*\(", open(header).read())))
     assert len(names) >= 17

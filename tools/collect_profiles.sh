@@ -3,17 +3,17 @@
 # Usage: gpurun -- 'bash tools/collect_profiles.sh r01'
 # Outputs land in gpurun_out/<tag>_*; tools/summarize_profiles.py turns them into profiles/<tag>_*.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --no-cpu-baseline --no-secondary"
-# kernel-trace + stats (no counters in these passes): the default command (steps on two streams: launches overlap, so the
-# per-launch duration exceeds a launch's share of the GPU) and the same with every step on one stream (the duration of a
-# launch on its own: what bench.py reports as roofline.one_launch_alone / single_stream)
+# kernel-trace + stats (no counters in these passes): the default command (every step on one stream: the duration of a
+# launch on its own) and the same with the steps alternating on two streams (launches overlap, so the per-launch duration
+# exceeds a launch's share of the GPU: what bench.py reports as two_streams_overlapped)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats --output-format csv -- $BENCH --steps 400 --warmup 50 > $OUT/${TAG}_stats.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats1 --output-format csv -- $BENCH --steps 400 --warmup 50 --streams 1 > $OUT/${TAG}_stats1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats2 --output-format csv -- $BENCH --steps 400 --warmup 50 --streams 2 > $OUT/${TAG}_stats2.log 2>&1
 # the counter passes run one launch at a time (--streams 1) over the six rotating batches (302 MB: beyond the Infinity Cache)
 BENCH="$BENCH --streams 1"
 # HBM traffic: FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots)
@@ -22,6 +22,15 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -
 # SQ issue/stall counters
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU -d $OUT/${TAG}_pmc_sq --output-format csv -- $BENCH --steps 20 --warmup 5 > $OUT/${TAG}_pmc_sq.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_SMEM -d $OUT/${TAG}_pmc_sq2 --output-format csv -- $BENCH --steps 20 --warmup 5 > $OUT/${TAG}_pmc_sq2.log 2>&1
+# the other kernels and K3's other variants, one process per case (tools/kernel_cases.py): kernel-trace stats, then
+# FETCH_SIZE and WRITE_SIZE in their own passes -- the HBM-bound K1 / K2 / K4 and the loss variants the headline does not run
+for c in ${CASES:-k1 k2 k4 k3_mixed k3_head k3_head_l1 k3_untied k3_config4 k3_config5}; do
+  timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_case_${c}_stats --output-format csv -- python3 $R/tools/kernel_cases.py $c 60 > $OUT/${TAG}_case_${c}.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_case_${c}_fetch --output-format csv -- python3 $R/tools/kernel_cases.py $c 12 >> $OUT/${TAG}_case_${c}.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_case_${c}_write --output-format csv -- python3 $R/tools/kernel_cases.py $c 12 >> $OUT/${TAG}_case_${c}.log 2>&1
+  # the raw per-dispatch traces are large: keep the stats and the counter tables only
+  find $OUT/${TAG}_case_${c}_stats $OUT/${TAG}_case_${c}_fetch $OUT/${TAG}_case_${c}_write -name '*_kernel_trace.csv' -delete 2>/dev/null
+done
 cd $R
 # un-profiled bench line (with the CPU baseline) -- never compare profiled and un-profiled timings
 timeout 400 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err

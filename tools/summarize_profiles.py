@@ -13,7 +13,7 @@ algorithmic reads; WRITE_SIZE is exact.
 import collections, csv, glob, json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 
@@ -28,7 +28,10 @@ if st:
     shutil.copy(st, os.path.join(P, "%s_kernel_stats.csv" % tag))                 # default command: two streams
 st1 = one("%s_stats1/*/*_kernel_stats.csv" % tag)
 if st1:
-    shutil.copy(st1, os.path.join(P, "%s_kernel_stats_streams1.csv" % tag))      # --streams 1: one launch at a time
+    shutil.copy(st1, os.path.join(P, "%s_kernel_stats_streams1.csv" % tag))      # round 2 layout: --streams 1 beside a two-stream default
+st2 = one("%s_stats2/*/*_kernel_stats.csv" % tag)
+if st2:
+    shutil.copy(st2, os.path.join(P, "%s_kernel_stats_streams2.csv" % tag))      # round 3: default = one stream; this = --streams 2
 summary = {}
 for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     f = one("%s_%s/*/*_counter_collection.csv" % (tag, p))
@@ -65,6 +68,43 @@ if k3 and "FETCH_SIZE" in summary[k3] and "WRITE_SIZE" in summary[k3]:
     json.dump(traffic, open(os.path.join(P, "k3_hbm_traffic.json"), "w"), indent=1)
     summary["_k3_traffic"] = traffic
 json.dump(summary, open(os.path.join(P, "%s_pmc_summary.json" % tag), "w"), indent=1, sort_keys=True)
+# ---- the other kernels / K3 variants (tools/kernel_cases.py, one process per case and pass)
+cases = {}
+for log in sorted(glob.glob(os.path.join(G, "%s_case_*.log" % tag))):
+    c = os.path.basename(log)[len(tag) + 6:-4]
+    info = [json.loads(l) for l in open(log) if l.startswith("{")]
+    if not info:
+        continue
+    kern, alg = info[0]["kernel"], info[0]["algorithmic_bytes_per_launch"]
+    row = {"case": c, "algorithmic_bytes_per_launch": alg}
+    stf = one("%s_case_%s_stats/*/*_kernel_stats.csv" % (tag, c))
+    if stf:
+        for r in csv.DictReader(open(stf)):
+            if kern in r["Name"]:
+                row.update(kernel=r["Name"][:160], calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3,
+                           min_us=float(r["MinNs"]) / 1e3, max_us=float(r["MaxNs"]) / 1e3)
+                row["algorithmic_GBps"] = alg / (row["avg_us"] * 1e-6) / 1e9
+                row["frac_of_8TBps"] = row["algorithmic_GBps"] / 8000.0
+                break
+    for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        cf = one("%s_case_%s_%s/*/*_counter_collection.csv" % (tag, c, which))
+        if cf:
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(cf))
+                 if kern in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if v:
+                row[counter + "_KiB_raw_mean"] = sum(v) / len(v)
+    if "FETCH_SIZE_KiB_raw_mean" in row and "WRITE_SIZE_KiB_raw_mean" in row:
+        row["read_bytes_x2_corrected"] = 2.0 * row["FETCH_SIZE_KiB_raw_mean"] * 1024.0
+        row["write_bytes"] = row["WRITE_SIZE_KiB_raw_mean"] * 1024.0
+        row["hbm_bytes_per_launch"] = row["read_bytes_x2_corrected"] + row["write_bytes"]
+        row["traffic_over_algorithmic"] = row["hbm_bytes_per_launch"] / alg
+    cases[c] = row
+if cases:
+    json.dump({"note": "rocprofv3 --kernel-trace --stats average duration per kernel and, from separate --pmc passes, FETCH_SIZE / "
+                       "WRITE_SIZE per launch (KiB; reads doubled per the gfx950 note of MI355X_MICROARCH.md: exact for 16 B per "
+                       "lane streaming reads, validated on K3's dword reads in round 2; the 8 B per lane reads of K2 are "
+                       "uncalibrated).  Working sets beyond the 256 MiB Infinity Cache (tools/kernel_cases.py).",
+               "cases": cases}, open(os.path.join(P, "%s_kernel_cases.json" % tag), "w"), indent=1, sort_keys=True)
 for name in ("k3_sweep.txt", "k12_bench.txt", "valu_rate.txt"):
     src = os.path.join(G, "%s_%s" % (tag, name))
     if os.path.exists(src):

@@ -36,7 +36,12 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=0,
                     help="ranks (one per GPU).  0: whatever the launcher's WORLD_SIZE says (1 without a launcher)")
-    ap.add_argument("--data", default="synthetic", help="'synthetic' or a directory of tiled PNG samples")
+    ap.add_argument("--data", default="synthetic",
+                    help="'synthetic': random SVBRDF maps drawn ON THE DEVICE, one batch per step, per-rank generator (no "
+                         "dataloader: one CPU worker produces ~60 synthetic samples/s, less than a training step consumes); "
+                         "'synthetic-cpu': the same statistics from a torch Dataset through the DataLoader / "
+                         "DistributedSampler (what --device cpu and --verify-global-batch use); or a directory of tiled "
+                         "PNG samples (the reference's SvbrdfDataset format)")
     ap.add_argument("--image-count", type=int, default=10, help="photos stored per tiled PNG")
     ap.add_argument("--scale-mode", choices=("crop", "resize"), default="crop")      # cli.py scale mode, dataset.py:58-89
     ap.add_argument("--random-crop", action="store_true")
@@ -58,7 +63,10 @@ def parse_args(argv=None):
     ap.add_argument("--fused-head", action="store_true", help="model returns 9 channels, head decoded in the loss kernel")
     ap.add_argument("--no-coords", action="store_true")
     ap.add_argument("--samples", type=int, default=0, help="synthetic dataset length (default: enough for --steps)")
-    ap.add_argument("--workers", type=int, default=2)
+    ap.add_argument("--workers", type=int, default=-1,
+                    help="DataLoader worker processes per rank; -1 = from the host: (cpus / ranks on this node) - 1, at "
+                         "least 2, at most 16 -- the tiled-PNG reader delivers ~45-60 samples/s per worker "
+                         "(tools/loader_rate.py), a training step consumes hundreds per GPU")
     ap.add_argument("--seed", type=int, default=313)                     # utils.py:7
     ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"))
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl on cuda, gloo on cpu)")
@@ -66,13 +74,17 @@ def parse_args(argv=None):
     ap.add_argument("--resume", default=None,
                     help="checkpoint to start from: one written by --save, or a checkpoint.tar of the reference "
                          "(persistence.py:52-69; model weights only)")
-    ap.add_argument("--conv-mode", choices=("reference", "fast", "autotune"), default="reference",
-                    help="how stock PyTorch-ROCm picks the U-Net's MIOpen convolution algorithms.  reference: "
-                         "cudnn.deterministic=True, benchmark=False as utils.py:11-12 sets them -- on ROCm that pins every "
-                         "convolution to MIOpen's im2col+GEMM algorithm, one GEMM per image (DESIGN.md section 10); fast: "
-                         "deterministic=False, benchmark=False -- MIOpen's immediate-mode heuristic choice, no search; "
-                         "autotune: benchmark=True -- MIOpen's find step times the candidates at the first call of every "
-                         "shape")
+    ap.add_argument("--conv-mode", choices=("hybrid", "reference", "fast", "autotune"), default="hybrid",
+                    help="how stock PyTorch-ROCm picks the U-Net's MIOpen convolution algorithms (DESIGN.md section 10).  "
+                         "reference: cudnn.deterministic=True, benchmark=False as utils.py:11-12 sets them -- on ROCm that "
+                         "pins EVERY convolution, forward and backward, to MIOpen's im2col+GEMM algorithm, one GEMM per "
+                         "image: fine forward, pathological backward (2.7 s per step at configs[3]); fast: "
+                         "deterministic=False, benchmark=False -- MIOpen's immediate-mode heuristic choice, no search: good "
+                         "backward, 5x slower forward; hybrid (default): the reference's setting while the network runs "
+                         "forward (same algorithms, same bits as the reference setting), the immediate-mode choice while "
+                         "autograd runs backward -- the flags are read when a convolution executes; autotune: "
+                         "benchmark=True -- MIOpen's find step compiles and times the candidates at the first call of "
+                         "every shape (7 min at config 2, > 15 min at configs[3] on a fresh box)")
     ap.add_argument("--autotune", action="store_true", help="same as --conv-mode autotune")
     ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights for the U-Net")
     ap.add_argument("--share-device", action="store_true",
@@ -148,9 +160,10 @@ def run(args):
         net = models.SingleViewModel(use_coords=not args.no_coords, decode=decode)
     # identical initial weights on every rank: DDP broadcasts rank 0's parameters at construction
     conv_mode = "autotune" if args.autotune else args.conv_mode
-    if conv_mode != "reference":                # enable_deterministic_random_engine set the reference's flags above
+    if conv_mode in ("fast", "autotune"):       # enable_deterministic_random_engine set the reference's flags above
         torch.backends.cudnn.deterministic = False
         torch.backends.cudnn.benchmark = conv_mode == "autotune"
+    hybrid = conv_mode == "hybrid" and on_gpu
     steps_done = 0
     if args.resume:
         ck = torch.load(args.resume, map_location="cpu", weights_only=False)
@@ -184,7 +197,13 @@ def run(args):
         loss_fn.rendering_loss.specular_configuration_count = args.specular_scenes
 
     total_steps = args.warmup + args.steps
-    if args.data == "synthetic":
+    if args.workers < 0:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        args.workers = max(2, min(16, (os.cpu_count() or 2) // max(1, local_world) - 1))
+    device_source = args.data == "synthetic" and on_gpu and not verify
+    if device_source:
+        dataset, args.workers = None, 0
+    elif args.data in ("synthetic", "synthetic-cpu"):
         n = args.samples or total_steps * args.batch * world
         dataset = data.SyntheticSvbrdfDataset(n, image_size=args.size, seed=args.seed)
     else:
@@ -192,16 +211,24 @@ def run(args):
                                        used_image_count=args.views, is_linear=args.linear_input,
                                        scale_mode=args.scale_mode, random_crop=args.random_crop,
                                        mix_materials=args.mix_materials)
-    if verify:
+    if device_source:
+        sampler = loader = None
+    elif verify:
         sampler = distributed.ContiguousShardSampler(len(dataset), args.batch, rank, world)
     else:
         sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True,
                                                                   seed=args.seed, drop_last=True) if world > 1 else None
-    loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch, sampler=sampler, shuffle=sampler is None,
-                                         num_workers=args.workers, pin_memory=on_gpu, drop_last=True,
-                                         persistent_workers=args.workers > 0)
+    if not device_source:
+        loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch, sampler=sampler, shuffle=sampler is None,
+                                             num_workers=args.workers, pin_memory=on_gpu, drop_last=True,
+                                             persistent_workers=args.workers > 0)
 
     def batches():
+        if device_source:
+            gen = torch.Generator(device=dev).manual_seed(distributed.rank_seed(args.seed * 7919, rank))
+            empty = torch.zeros(args.batch, 0, 3, args.size, args.size)
+            while True:
+                yield {"inputs": empty, "svbrdf": data.synthetic_svbrdf_batch(args.batch, args.size, dev, gen)}
         epoch = 0
         while True:
             if sampler is not None and hasattr(sampler, "set_epoch"):
@@ -243,6 +270,8 @@ def run(args):
         if timing:
             marks.append(mark())
         out = model(net_in)
+        if hybrid:      # forward ran under the reference's flags (im2col+GEMM); backward takes MIOpen's immediate-mode choice
+            torch.backends.cudnn.deterministic = False
         if timing:
             marks.append(mark())
         if verify and args.loss != "l1":                                         # the scenes of the lower ranks' items
@@ -264,6 +293,8 @@ def run(args):
         if timing:
             marks.append(mark())
         optimizer.step()
+        if hybrid:
+            torch.backends.cudnn.deterministic = True
         losses_seen.append(loss.detach())
         if timing:
             marks.append(mark())
@@ -294,7 +325,7 @@ def run(args):
               "loss_first_quarter": first, "loss_last_quarter": last,
               "config": {"model": args.model, "views": args.views, "size": args.size, "per_gpu_batch": args.batch,
                          "scenes": args.random_scenes + args.specular_scenes, "fused_head": bool(args.fused_head),
-                         "data": args.data if args.data == "synthetic" else "tiled-png",
+                         "data": ("synthetic (device)" if device_source else args.data) if args.data.startswith("synthetic") else "tiled-png",
                          "workers": args.workers, "conv_mode": conv_mode, "channels_last": bool(args.channels_last)}}
     if timing:
         result["phase_ms_mean"] = {k: sum(v) / max(1, len(v)) for k, v in phase_ms.items()}
