@@ -222,9 +222,11 @@ def secondary_kernels(dev, H):
         tab = environment.BatchSceneSampler(B, n_random, n_specular).sample()
         tab = tab if B * (n_random + n_specular) <= _native.host_scenes_max_rows() else tab.to(dev)
         call = lambda: _native.rendering_loss(a, t, tab, 0.1, want_grad=True)
-        for _ in range(5):
-            call()
-        torch.cuda.synchronize(dev)
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < 0.2:
+            for _ in range(20):
+                call()
+            torch.cuda.synchronize(dev)
         # the ctypes binding costs ~50 us of host time per call, more than the kernel at config 2: events around EVERY
         # launch give the kernel's own duration (median), the wall time of the loop the call rate of this binding
         pairs = []
@@ -256,8 +258,12 @@ def secondary_kernels(dev, H):
                 a, t = sets[k % 4]
                 a.grad = None
                 loss_fn(a, t).backward()
-        run(60)
-        torch.cuda.synchronize(dev)
+        # settle by TIME, not by step count: right after the host-side generation of a new batch size the first ~100 ms of a
+        # leg have been seen running 3-4x slow (host-bound; not reproducible in isolation: profiles/r03_dbg_mixed*.txt)
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < 0.3:
+            run(60)
+            torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         run(300)
         torch.cuda.synchronize(dev)
@@ -489,11 +495,19 @@ def main():
     if dist is not None:
         barrier()
     torch.cuda.synchronize(dev)
+    # one HIP event pair around the WHOLE timed region, on the stream the kernels are launched on (one stream only: with
+    # N streams there is no single stream that sees every launch): region / launches is the average launch duration
+    # including the ~1 us between back-to-back launches, without the end-of-pipe bubbles of per-launch events
+    region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if not ns else None
     t0 = time.perf_counter()
+    if region:
+        region[0].record(torch.cuda.current_stream(dev))
     for i in range(args.steps):
         state["i"] = i
         last = step()
     state["i"] = -1
+    if region:
+        region[1].record(torch.cuda.current_stream(dev))
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0      # this rank's K steps are done; the job's time is the MAX over ranks (below)
     if dist is not None:
@@ -520,6 +534,7 @@ def main():
 
     kernel_ms = sorted(p[0].elapsed_time(p[1]) for p in ev if p is not None)
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    region_ms_per_launch = region[0].elapsed_time(region[1]) / args.steps if region else None
 
     # ---- untimed follow-up phases (same process, same tensors): the shader clock under this load, and the OTHER way of
     # issuing the steps (the timed region ran them on one stream -> now alternating on two, and vice versa)
@@ -597,9 +612,12 @@ def main():
         # time one launch takes out of the timed region.  With one stream that is the launch's own event-bracketed
         # duration; with N streams launches overlap (each takes longer, event-bracketed, than its share of the GPU), so
         # the share is what the roofline is priced with: timed region / launches (host-bound gaps count against the kernel).
-        share_ms = ms_per_step if n_streams > 1 else kernel_ms_avg
+        share_ms = ms_per_step if n_streams > 1 else region_ms_per_launch
         achieved = alg_bytes / (share_ms * 1e-3) / 1e9
-        achieved_one = alg_bytes / (one_kernel_avg * 1e-3) / 1e9
+        # one launch at a time: the region events of a single-stream timed region; in a follow-up leg (no region pair) the
+        # leg's wall time per step, which on one stream bounds the launch duration from above
+        one_launch_ms = region_ms_per_launch if main_ns == 0 else one["ms_per_step"]
+        achieved_one = alg_bytes / (one_launch_ms * 1e-3) / 1e9
         achieved_two = alg_bytes / (two["ms_per_step"] * 1e-3) / 1e9
         traffic = valu_issue = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "k3_hbm_traffic.json")
@@ -681,10 +699,11 @@ def main():
                          "achieved_definition": ("algorithmic bytes per launch / time per launch in the timed region "
                                                  "(timed region / launches: launches on %d streams overlap)" % n_streams)
                                                 if n_streams > 1 else
-                                                "algorithmic bytes per launch / average event-bracketed launch duration",
+                                                "algorithmic bytes per launch / average launch duration = HIP events around the "
+                                                "timed region on the launch stream / launches (back-to-back launches on one stream)",
                          "time_per_launch_ms": share_ms,
                          "one_launch_alone": {"achieved": achieved_one, "frac": achieved_one / HBM_PEAK_GBPS,
-                                              "kernel_ms_avg": one_kernel_avg},
+                                              "ms_per_launch": one_launch_ms, "sampled_event_pairs_ms_avg": one_kernel_avg},
                          "frac_of_measured_copy_peak": achieved / 6290.0,   # MI355X_MICROARCH.md: float4 copy
                          "kernel": "%s<GRAD=true,L1=false,HEAD=false> (single launch: both shadings, log/L1, adjoint, loss finalise)"
                                    % ("k_rendering_loss_inl" if B * S <= _native.host_scenes_max_rows() else "k_rendering_loss"),
@@ -692,8 +711,10 @@ def main():
                                         if B * S <= _native.host_scenes_max_rows() else "pinned-ring upload",
                          "kernel_limited_patches_per_s": B / (share_ms * 1e-3),
                          "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
-                         "kernel_ms_note": "event-bracketed duration of a launch in the timed region (with N > 1 streams it "
-                                           "overlaps its neighbours and exceeds time_per_launch_ms)",
+                         "kernel_ms_note": "event pairs around a SAMPLE of the launches of the timed region (every 32nd): each pair "
+                                           "costs its stream an end-of-pipe bubble and reads ~10 % long on a back-to-back stream; "
+                                           "with N > 1 streams a launch overlaps its neighbours and exceeds time_per_launch_ms.  The "
+                                           "roofline is priced with time_per_launch_ms",
                          "launches_in_flight": n_streams,
                          "kernel_launches_timed": len(kernel_ms),
                          "algorithmic_bytes_per_launch": alg_bytes,

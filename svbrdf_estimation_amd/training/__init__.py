@@ -3,3 +3,23 @@ Deschaintre U-Net (stock PyTorch-ROCm modules, no custom kernels), the tiled-PNG
 and a one-process-per-GPU DDP harness (RCCL all-reduce of the U-Net gradients; the rendering
 loss itself shards by batch with no collective).  See train.py at the repository root."""
 from . import data, models  # noqa: F401
+
+
+def use_in_tree_miopen_cache():
+    """The image ships no gfx950 MIOpen database, so on a fresh box the U-Net's first steps compile (and, for every new
+    convolution shape, search) their kernels: 35 s at config 2, 5 min at configs[3].  MIOpen keeps what it built in a
+    user cache; when ``svbrdf_estimation_amd/training/miopen_cache/`` exists (kernel binaries + find results written by an
+    earlier run on an MI355X: ``tools/profile_train.sh`` packs them, ``tools/install_miopen_cache.sh`` unpacks them
+    here; git-ignored like every built artefact) and the user has not pointed MIOpen elsewhere, use it.  Purely a
+    compile/search cache: the kernels are the ones a fresh box builds for itself.  Must run before the first
+    convolution of the process.  Returns the directory used, or None."""
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_cache")
+    if not os.path.isdir(os.path.join(here, "cache")):
+        return None
+    if "MIOPEN_CUSTOM_CACHE_DIR" in os.environ or "MIOPEN_USER_DB_PATH" in os.environ:
+        return None
+    os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(here, "cache")
+    if os.path.isdir(os.path.join(here, "db")):
+        os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(here, "db")
+    return here

@@ -9,6 +9,12 @@ for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
         sys.path.insert(0, p)
 
 
+# the in-process training tests run MIOpen convolutions: use the in-tree kernel cache when one has been installed
+from svbrdf_estimation_amd.training import use_in_tree_miopen_cache  # noqa: E402
+
+use_in_tree_miopen_cache()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

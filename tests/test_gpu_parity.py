@@ -713,9 +713,13 @@ def test_retain_graph_allows_a_second_backward_like_plain_autograd(dev, golden):
         assert torch.equal(x.grad, once + 0.5 * once)
         loss.backward()                                                          # last one: may consume the buffer
         assert torch.equal(x.grad, (once + 0.5 * once) + once)
-        with pytest.raises(RuntimeError):
+        if make is via_module:          # the native node has given its buffer away: a freed graph, and it says so
+            with pytest.raises(RuntimeError):
+                loss.backward()
+        else:                           # the ctypes fallback saves no graph tensors (like y = x + 1): still differentiable
             loss.backward()
-        w = torch.full((1,), 2.0, device=dev, requires_grad=True)               # non-leaf input (the training case)
+            assert torch.equal(x.grad, ((once + 0.5 * once) + once) + once)
+        w = torch.full((1,), 1.0, device=dev, requires_grad=True)               # non-leaf input (the training case)
         loss = make(_t(g["input"], dev) * w)
         (g1,) = torch.autograd.grad(loss, w, retain_graph=True)
         (g2,) = torch.autograd.grad(loss, w)
@@ -916,15 +920,12 @@ def test_config4_batch16_mixed_loss_module_path(dev, native, oracle):
     assert again[0].item() == res[0][0] and torch.equal(again[1], res[0][1])
 
 
-@pytest.mark.timeout(900)
-@pytest.mark.skipif(not os.environ.get("SVBRDF_SLOW_TESTS"),
-                    reason="~5 min on a fresh box, nearly all of it MIOpen compiling convolution kernels for the 80-image "
-                           "batch (stock PyTorch-ROCm, outside the hot path); run with SVBRDF_SLOW_TESTS=1 -- the last run's "
-                           "output is committed as profiles/r02_config4_train.json.  The loss kernels at this configuration "
-                           "are covered by test_config4_batch16_mixed_loss_module_path, which always runs")
+@pytest.mark.timeout(1200)
 def test_config4_training_harness_multi_view_5_batch_16(dev):
     """configs[3] through train.py: multi-view network (N = 5 photos, pooled encoder, models.py:348-411), batch 16,
-    mixed loss, photos synthesised on the GPU -- a few steps at size"""
+    mixed loss, photos synthesised on the GPU -- two steps at size.  1 s with the in-tree MIOpen cache installed
+    (tools/install_miopen_cache.sh; the driver's snapshot carries it), ~5 min of MIOpen kernel compilation on a box
+    without it (the image ships no gfx950 database) -- slow then, not wrong."""
     import train
     args = train.parse_args(["--model", "multi", "--views", "5", "--batch", "16", "--steps", "1", "--warmup", "1",
                              "--workers", "0", "--samples", "16"])

@@ -107,9 +107,10 @@ def parse_args(argv=None):
 
 
 def run(args):
-    from svbrdf_estimation_amd import distributed, losses, renderers, utils
+    from svbrdf_estimation_amd import distributed, losses, renderers, training, utils
     from svbrdf_estimation_amd.training import data, models
     import torch.distributed as dist
+    miopen_cache = training.use_in_tree_miopen_cache()      # before the first convolution of the process
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -326,7 +327,8 @@ def run(args):
               "config": {"model": args.model, "views": args.views, "size": args.size, "per_gpu_batch": args.batch,
                          "scenes": args.random_scenes + args.specular_scenes, "fused_head": bool(args.fused_head),
                          "data": ("synthetic (device)" if device_source else args.data) if args.data.startswith("synthetic") else "tiled-png",
-                         "workers": args.workers, "conv_mode": conv_mode, "channels_last": bool(args.channels_last)}}
+                         "workers": args.workers, "conv_mode": conv_mode, "channels_last": bool(args.channels_last),
+                         "miopen_cache": "in-tree" if miopen_cache else "the user's / MIOpen's default"}}
     if timing:
         result["phase_ms_mean"] = {k: sum(v) / max(1, len(v)) for k, v in phase_ms.items()}
         result["phase_note"] = "per-step means over the timed steps; one device synchronisation per step (not a throughput run)"
