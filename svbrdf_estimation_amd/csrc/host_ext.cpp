@@ -32,6 +32,9 @@ namespace {
 
 using loss_fn_t = int (*)(const float *, const float *, const float *, const float *, float, float, float, float *,
                           float *, void *, size_t, int, int, int, int, void *);
+using render_fwd_fn_t = int (*)(const float *, const float *, int, const float *, float *, int, int, int, int, void *);
+using render_bwd_fn_t = int (*)(const float *, const float *, int, const float *, const float *, float *, int, int, int,
+                                int, void *);
 using scale_fn_t = int (*)(float *, const float *, size_t, void *);
 using ws_fn_t = size_t (*)(int, int, int, int);
 using err_fn_t = const char *(*)();
@@ -45,6 +48,8 @@ struct Abi {
     loss_fn_t head = nullptr;     // same signature, input = [B,9,H,W] encoded head output
     loss_fn_t mixed_host = nullptr, head_host = nullptr;   // scene table in host memory (kernel-argument block)
     int host_rows = 0;            // largest B*S those two take
+    render_fwd_fn_t render_fwd_host = nullptr;             // K1 / K2 with the scene rows by value (svbrdf_hip.h)
+    render_bwd_fn_t render_bwd_host = nullptr;
     scale_fn_t scale = nullptr;
     ws_fn_t ws_bytes = nullptr;
     err_fn_t last_error = nullptr;
@@ -68,6 +73,8 @@ void bind(const std::string &path)
     g_abi.mixed_host = reinterpret_cast<loss_fn_t>(need("svbrdf_mixed_loss_fwd_bwd_host_scenes"));
     g_abi.head_host = reinterpret_cast<loss_fn_t>(need("svbrdf_head_loss_fwd_bwd_host_scenes"));
     g_abi.host_rows = reinterpret_cast<int (*)()>(need("svbrdf_host_scenes_max_rows"))();
+    g_abi.render_fwd_host = reinterpret_cast<render_fwd_fn_t>(need("svbrdf_render_fwd_host_scenes"));
+    g_abi.render_bwd_host = reinterpret_cast<render_bwd_fn_t>(need("svbrdf_render_bwd_host_scenes"));
     g_abi.scale = reinterpret_cast<scale_fn_t>(need("svbrdf_scale_inplace"));
     g_abi.ws_bytes = reinterpret_cast<ws_fn_t>(need("svbrdf_rendering_loss_workspace_bytes"));
     g_abi.last_error = reinterpret_cast<err_fn_t>(need("svbrdf_last_error"));
@@ -448,6 +455,91 @@ at::Tensor fused_loss_with_scenes(const at::Tensor &input, const at::Tensor &tar
     return run_fused(input, target, scenes.contiguous(), eps, l1_weight, eps_l1, stream, head);
 }
 
+// ------------------------------------------------------------------------------------------
+// LocalRenderer.render(scene, svbrdf) without the interpreter in the loop: K1 with the scene's rows by value, and a
+// plain autograd node whose apply() launches K2.  `rows` is the HOST [S,9] table shared by every map of the batch
+// (renderers.py:98: one scene, B maps); it is copied into the node (9*S floats), nothing of the caller's is retained.
+// ------------------------------------------------------------------------------------------
+struct RenderBackward : public torch::autograd::Node {
+    torch::autograd::SavedVariable maps;      // version-checked like any saved input
+    std::vector<float> rows;
+    at::Tensor xrow;
+    int B = 0, S = 0, H = 0, W = 0;
+    void *stream = nullptr;
+
+    torch::autograd::variable_list apply(torch::autograd::variable_list &&grads) override
+    {
+        torch::autograd::variable_list out(1);
+        if (!task_should_compute_output(0)) return out;
+        const auto m = maps.unpack(shared_from_this());
+        TORCH_CHECK(m.defined(), "Trying to backward through LocalRenderer.render a second time: the saved maps were freed; "
+                                 "specify retain_graph=True for the first backward");
+        at::AutoDispatchBelowADInplaceOrView below_autograd;
+        const auto go = grads[0].contiguous();
+        TORCH_CHECK(go.scalar_type() == at::kFloat && go.numel() == (int64_t)B * S * 3 * H * W, "render backward: bad cotangent");
+        auto grad = at::empty_like(m);
+        check(g_abi.render_bwd_host(m.data_ptr<float>(), rows.data(), 1, xrow.data_ptr<float>(), go.data_ptr<float>(),
+                                    grad.data_ptr<float>(), B, S, H, W, stream), "svbrdf_render_bwd_host_scenes");
+        out[0] = std::move(grad);
+        return out;
+    }
+
+    void release_variables() override { maps.reset_data(); }
+
+    std::string name() const override { return "SvbrdfRenderBackward"; }
+};
+
+// maps [B,12,H,W] on the device, rows: HOST fp32 [S,9] shared by all maps -> [B,S,3,H,W]
+at::Tensor render_shared_scenes(const at::Tensor &maps_in, const at::Tensor &rows, int64_t stream)
+{
+    TORCH_CHECK(g_abi.render_fwd_host != nullptr, "host extension not bound to libsvbrdf_hip.so (call bind first)");
+    TORCH_CHECK(maps_in.dim() == 4 && maps_in.size(1) == 12 && maps_in.size(2) == maps_in.size(3),
+                "svbrdf must be [B,12,H,W] with H == W");
+    TORCH_CHECK(maps_in.is_cuda() && maps_in.scalar_type() == at::kFloat,
+                "the MI355X engine only computes on fp32 tensors on a ROCm device (no CPU fallback)");
+    TORCH_CHECK(rows.is_cpu() && rows.scalar_type() == at::kFloat && rows.dim() == 2 && rows.size(1) == 9 &&
+                    rows.is_contiguous() && rows.size(0) >= 1 && rows.size(0) <= g_abi.host_rows,
+                "rows must be a contiguous host fp32 [S,9] table of at most ", g_abi.host_rows, " scenes");
+    const int B = (int)maps_in.size(0), S = (int)rows.size(0), H = (int)maps_in.size(2), W = (int)maps_in.size(3);
+    at::Tensor xrow;
+    {
+        std::lock_guard<std::mutex> lock(g_state.mu);
+        const int dev = maps_in.device().index();
+        if (g_state.device != dev) {
+            g_state.workspace_by_stream.clear();
+            g_state.xrow_by_width.clear();
+            g_state.device = dev;
+        }
+        auto &xr = g_state.xrow_by_width[W];
+        if (!xr.defined()) {
+            auto host = at::empty({W}, at::TensorOptions().dtype(at::kFloat));
+            check(g_abi.make_xrow(host.data_ptr<float>(), W), "svbrdf_make_xrow");
+            xr = host.to(maps_in.device());
+        }
+        xrow = xr;
+    }
+    void *st = reinterpret_cast<void *>(stream);
+    at::Tensor out, maps;
+    {
+        at::AutoDispatchBelowADInplaceOrView below_autograd;
+        maps = maps_in.contiguous();
+        out = at::empty({B, S, 3, H, W}, maps.options());
+        check(g_abi.render_fwd_host(maps.data_ptr<float>(), rows.data_ptr<float>(), 1, xrow.data_ptr<float>(),
+                                    out.data_ptr<float>(), B, S, H, W, st), "svbrdf_render_fwd_host_scenes");
+    }
+    if (at::GradMode::is_enabled() && maps_in.requires_grad()) {
+        auto node = std::shared_ptr<RenderBackward>(new RenderBackward(), torch::autograd::deleteNode);
+        node->set_next_edges(torch::autograd::collect_next_edges(maps_in));
+        node->maps = torch::autograd::SavedVariable(maps_in.is_contiguous() ? maps_in : maps, false);
+        node->rows.assign(rows.data_ptr<float>(), rows.data_ptr<float>() + (size_t)S * 9);
+        node->xrow = xrow;
+        node->B = B; node->S = S; node->H = H; node->W = W;
+        node->stream = st;
+        torch::autograd::set_history(out, node);
+    }
+    return out;
+}
+
 // `loss.backward()` on a LEAF input without the engine.  The kernel has already produced d loss / d input for upstream
 // gradient 1, which is exactly what a plain loss.backward() asks for, so the engine's work for that call -- a fill
 // kernel for the implicit ones tensor, a graph task, this node's no-op scale launch, AccumulateGrad -- reduces to
@@ -510,4 +602,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("fused_loss_with_scenes", &fused_loss_with_scenes);
     m.def("sample_scene_table", &sample_scene_table);
     m.def("fast_backward", &fast_backward);
+    m.def("render_shared_scenes", &render_shared_scenes);
 }

@@ -15,7 +15,7 @@ map in one launch, reading the maps once.
 """
 import torch
 
-from . import _native, environment
+from . import _hostext, _native, environment
 
 
 class _RenderFunction(torch.autograd.Function):
@@ -53,7 +53,12 @@ class LocalRenderer:
         # the scene's nine floats stay on the host and travel with the launch: one dispatch per call, no H2D copy
         # (the reference uploads camera, light and colour with three synchronous copies, renderers.py:79,91,98)
         row = environment.scene_to_row(scene).view(1, 9)           # one scene, shared by every map of the batch
-        out = _RenderFunction.apply(maps, row)                     # raises on non-ROCm tensors
+        ext = _hostext.module() if maps.is_cuda else None
+        if ext is not None and maps.dtype == torch.float32 and maps.device.index == torch.cuda.current_device():
+            # native host path (csrc/host_ext.cpp): same two kernels through the same C ABI, C++ autograd node
+            out = ext.render_shared_scenes(maps, row, _native._raw_stream(maps.device))
+        else:
+            out = _RenderFunction.apply(maps, row)                 # ctypes path; raises on non-ROCm tensors
         return out.view(maps.shape[0], 3, maps.shape[-2], maps.shape[-1])
 
     def render_many(self, scene_table, svbrdf):

@@ -187,3 +187,25 @@ def test_contiguous_shard_sampler_tiles_the_global_batches():
     for k in range(2):
         block = sum((s[k * per:(k + 1) * per] for s in seen), [])
         assert block == list(range(k * 12, (k + 1) * 12))
+
+
+def test_resume_accepts_both_checkpoint_layouts_and_counts_steps(tmp_path):
+    """train.py --resume: a checkpoint in the reference's parameter names (what --save writes and what the reference's
+    persistence.py writes) and one in this package's own names (written by --save before it switched layouts) both
+    load; the step count carries over into the next --save."""
+    import train
+    from svbrdf_estimation_amd.training import models
+    torch.manual_seed(0)
+    net = models.SingleViewModel()
+    own, ref = str(tmp_path / "own.tar"), str(tmp_path / "ref.tar")
+    torch.save({"model_state_dict": net.state_dict(), "steps": 7}, own)
+    torch.save({"model_state_dict": models.convert_to_reference_state_dict(net.state_dict()), "steps": 5}, ref)
+    torch.set_num_threads(4)
+    for src, before in ((own, 7), (ref, 5)):
+        out = str(tmp_path / "out.tar")
+        train.run(train.parse_args(["--device", "cpu", "--loss", "l1", "--steps", "1", "--warmup", "0", "--batch", "1",
+                                    "--workers", "0", "--resume", src, "--save", out, "--lr", "0"]))
+        ck = torch.load(out, map_location="cpu", weights_only=False)
+        assert ck["steps"] == before + 1
+        back = models.convert_reference_state_dict(ck["model_state_dict"])
+        assert all(torch.equal(back[k], v) for k, v in net.state_dict().items())       # lr 0: the weights are the loaded ones
