@@ -50,6 +50,9 @@ class LocalRenderer:
             maps = svbrdf
         else:
             raise ValueError("svbrdf must be [12,H,W] or [B,12,H,W], got %s" % (tuple(svbrdf.shape),))
+        if maps.shape[1] != 12 or maps.shape[-1] != maps.shape[-2]:
+            raise ValueError("svbrdf must have 12 channels and H == W (the reference transposes the x grid, "
+                             "renderers.py:75), got %s" % (tuple(svbrdf.shape),))
         # the scene's nine floats stay on the host and travel with the launch: one dispatch per call, no H2D copy
         # (the reference uploads camera, light and colour with three synchronous copies, renderers.py:79,91,98)
         row = environment.scene_to_row(scene).view(1, 9)           # one scene, shared by every map of the batch
