@@ -437,13 +437,16 @@ def main():
     loss_fn.specular_configuration_count = args.specular_scenes
     torch.manual_seed(distributed.rank_seed(313, rank))    # per-rank scene RNG
 
-    # HIP events around the kernel launch on the launch stream, on every `stride`-th timed step (a timing
-    # event is an end-of-pipe timestamp: bracketing EVERY launch costs ~10 us of GPU idle per step once the
-    # loop is GPU-bound, so the launches are sampled instead: every 32nd at the default 2000 steps = 63 samples,
-    # and at least 2 samples however few steps are asked for)
-    stride = max(1, min(32, args.steps // 2))
+    # HIP events around individual kernel launches on the launch stream, on every 32nd timed step (a timing event is an
+    # end-of-pipe timestamp: each bracketed launch costs its stream ~10 us of idle once the loop is GPU-bound, so the
+    # launches are sampled: 63 samples at the default 2000 steps).  A short timed region (the driver's --steps 20 is 0.8 ms)
+    # gets NO per-launch events -- two bubbles would be 2.5 % of it -- and the samples are taken in an untimed leg right
+    # after it instead.  The roofline is priced with the ONE event pair around the whole region either way.
+    sample_in_region = args.steps >= 256
+    n_sample_leg = args.steps if sample_in_region else 128
+    stride = 32 if sample_in_region else 16
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          if i % stride == 0 else None for i in range(args.steps)]
+          if i % stride == 0 else None for i in range(n_sample_leg)]
     state = {"i": -1}
 
     def hook(phase):
@@ -503,7 +506,8 @@ def main():
     if region:
         region[0].record(torch.cuda.current_stream(dev))
     for i in range(args.steps):
-        state["i"] = i
+        if sample_in_region:
+            state["i"] = i
         last = step()
     state["i"] = -1
     if region:
@@ -532,6 +536,16 @@ def main():
     else:
         mean_loss = last.item()
 
+    if not sample_in_region:                # untimed: the per-launch event samples a short timed region does not carry
+        _native.set_launch_hook(hook)
+        for i in range(n_sample_leg):
+            state["i"] = i
+            step()
+        state["i"] = -1
+        torch.cuda.synchronize(dev)
+        _native.set_launch_hook(None)
+        if ns:
+            torch.cuda.set_stream(torch.cuda.default_stream(dev))
     kernel_ms = sorted(p[0].elapsed_time(p[1]) for p in ev if p is not None)
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
     region_ms_per_launch = region[0].elapsed_time(region[1]) / args.steps if region else None
@@ -711,7 +725,8 @@ def main():
                                         if B * S <= _native.host_scenes_max_rows() else "pinned-ring upload",
                          "kernel_limited_patches_per_s": B / (share_ms * 1e-3),
                          "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
-                         "kernel_ms_note": "event pairs around a SAMPLE of the launches of the timed region (every 32nd): each pair "
+                         "kernel_ms_note": "event pairs around a SAMPLE of the launches (every 32nd of the timed region; for a region "
+                                           "shorter than 256 steps: every 16th of an untimed 128-step leg right after it): each pair "
                                            "costs its stream an end-of-pipe bubble and reads ~10 % long on a back-to-back stream; "
                                            "with N > 1 streams a launch overlaps its neighbours and exceeds time_per_launch_ms.  The "
                                            "roofline is priced with time_per_launch_ms",

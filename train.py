@@ -181,8 +181,9 @@ def run(args):
                 m.p = 0.0
     if args.channels_last:
         net = net.to(memory_format=torch.channels_last)
-    model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank] if on_gpu else None) \
-        if grouped else net
+    # gradient_as_bucket_view: the parameters' .grad ARE views of the all-reduce buckets (no 320 MB copy per step)
+    model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank] if on_gpu else None,
+                                                      gradient_as_bucket_view=True) if grouped else net
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
     if args.resume and "optimizer_state_dict_amd" in ck:
         optimizer.load_state_dict(ck["optimizer_state_dict_amd"])
