@@ -605,6 +605,20 @@ def main():
     ns = main_ns
     other_ms = sorted(p[0].elapsed_time(p[1]) for p in ev_other if p is not None)
     other_ms_avg = sum(other_ms) / len(other_ms)
+    # one more untimed leg, one stream: `loss.backward()` through PyTorch's autograd engine instead of the engine-free
+    # accumulate a LEAF input gets (losses._FusedLossTensor).  A network output -- the training case -- always takes the
+    # engine, so this is the step rate of the loss as a node of a larger graph.
+    saved_ns, ns = ns, 0
+    saved_fast, losses._FAST_BACKWARD = losses._FAST_BACKWARD, False
+    for _ in range(64):
+        step()
+    torch.cuda.synchronize(dev)
+    t_engine = time.perf_counter()
+    for _ in range(other_steps):
+        step()
+    torch.cuda.synchronize(dev)
+    engine_ms_per_step = 1e3 * (time.perf_counter() - t_engine) / other_steps
+    losses._FAST_BACKWARD, ns = saved_fast, saved_ns
 
     if rank == 0:
         patches = world * B * args.steps
@@ -736,6 +750,12 @@ def main():
                          "valu_frac_of_fp32_peak": (FLOP_PER_PIXEL_SCENE * H * H * S * B / (share_ms * 1e-3))
                                                    / (FP32_VALU_PEAK_TFLOPS * 1e12),
                          "valu_issue": valu_issue},
+            "single_stream_through_autograd_engine": {
+                "patches_per_s": B / (engine_ms_per_step * 1e-3), "ms_per_step": engine_ms_per_step, "steps": other_steps,
+                "note": "per GPU, follow-up leg: the same step with loss.backward() going through PyTorch's autograd engine "
+                        "(ones-fill kernel, graph task, the node's no-op scale launch, AccumulateGrad) -- what the loss costs as "
+                        "a node of a larger graph (a network output); `value` uses the engine-free accumulate that a plain "
+                        "loss.backward() on a LEAF input resolves to (%s)" % ("enabled" if saved_fast else "disabled on this torch version")},
             "loss": mean_loss,
             "host_path": "native C++ extension (csrc/host_ext.cpp)" if ext is not None else "python + ctypes",
             "autograd_engine": "multithreaded" if args.engine_threads else "calling thread",

@@ -339,7 +339,7 @@ def test_seeded_sweep_of_shapes_and_map_statistics_against_the_oracle(dev, nativ
                          (0.1, lambda **k: oracle.mixed_loss(inp, tgt, table, **k))):
             ref_l, ref_g = ofn()
             _, g64 = ofn(f64=True)
-            loss, grad = native.rendering_loss(d_in, d_tg, table if trial % 2 else d_sc, l1_weight=l1w)   # host and device tables
+            loss, grad = native.rendering_loss(d_in, d_tg, torch.from_numpy(table) if trial % 2 else d_sc, l1_weight=l1w)   # host / device table
             assert_loss_close(loss.item(), ref_l, what)
             # (the exact-end-of-range cases render input and target equally dark at a few dozen pixels: exact ties)
             assert_grad_close(_np(grad), ref_g, what + " loss grad l1=%.1f" % l1w, f64=g64, tie_map=tie, max_ties=48)
