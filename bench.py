@@ -259,7 +259,7 @@ def secondary_kernels(dev, H):
                 a.grad = None
                 loss_fn(a, t).backward()
         # settle by TIME, not by step count: right after the host-side generation of a new batch size the first ~100 ms of a
-        # leg have been seen running 3-4x slow (host-bound; not reproducible in isolation: profiles/r03_dbg_mixed*.txt)
+        # leg have been seen running 3-4x slow (host-bound: the intra-op pool's workers still spinning, see main())
         t_settle = time.perf_counter()
         while time.perf_counter() - t_settle < 0.3:
             run(60)
@@ -295,9 +295,11 @@ def secondary_kernels(dev, H):
                 else:
                     x.grad = None
                     R.render(scene, x).backward(cot)
-            for _ in range(50):
-                call()
-            torch.cuda.synchronize(dev)
+            t_settle = time.perf_counter()          # settle by time (see k3_module below)
+            while time.perf_counter() - t_settle < 0.3:
+                for _ in range(50):
+                    call()
+                torch.cuda.synchronize(dev)
             n = 500
             t0 = time.perf_counter()
             for _ in range(n):
@@ -397,6 +399,12 @@ def main():
     if args.plumbing_only:
         return plumbing_only(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # The rank's own CPU work is tiny tensors (the scene sampler).  With torch's default intra-op pool -- one thread per
+    # core, 256 on the GPU box -- every host-side tensor op that does go parallel (generating the synthetic maps) leaves
+    # the pool's workers spinning for ~100-200 ms afterwards, and the launch path of the main thread ran 3-4x slow for that
+    # long (seen as a host-bound first leg after each new batch size; profiles/r03_dbg_mixed*.txt).  A small pool, and
+    # time-based settling before every timed leg.  (The CPU baseline sets its own thread counts.)
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 1) // max(1, world))))
     if not args.share_device and torch.cuda.device_count() < world:
         raise SystemExit("--gpus %d but only %d device(s) visible" % (world, torch.cuda.device_count()))
     if args.share_device:

@@ -154,6 +154,8 @@ def run(args):
     verify = args.verify_global_batch
     # per-rank scene RNG -- or, for --verify-global-batch, one stream shared by all ranks (each skips the others' draws)
     utils.enable_deterministic_random_engine(args.seed if verify else distributed.rank_seed(args.seed, rank))
+    if on_gpu:      # the rank's own CPU work is tiny (scene sampler, collation): a big intra-op pool only spins (bench.py main)
+        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
     decode = not args.fused_head
     if args.model == "multi":
         net = models.MultiViewModel(use_coords=not args.no_coords, decode=decode)
