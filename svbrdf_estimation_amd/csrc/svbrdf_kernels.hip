@@ -925,10 +925,18 @@ __device__ __forceinline__ void loss_pixel_scene_any(const VConst &K, const Geom
 // The adjoint kernel sits at the 128-VGPR limit of 4 waves/SIMD and spills a little either way; the
 // LDS variant keeps the scalars live across the interleaved streams and spills more.  So: LDS for
 // the forward-only kernels, prefetched global loads for the forward+adjoint kernels.
+#ifndef SVBRDF_K3_REMAT_TARGET
+#define SVBRDF_K3_REMAT_TARGET 0      // experiment: reload + re-prepare the target maps in every pass
+#endif
+struct RematTarget {                  // where the target's planes of this pixel live (experiment only)
+    const float *base;
+    size_t plane, pix;
+};
+
 template <int NL, bool WITH_GRAD>
-__device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt, float x, float y,
+__device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt_in, float x, float y,
                                                  const float *__restrict__ scp, const float *sc_lds, int S,
-                                                 float eps, float inv_count, Grad &acc)
+                                                 float eps, float inv_count, Grad &acc, RematTarget rt = RematTarget{nullptr, 0, 0})
 {
     float lsum = 0.0f;
     const VConst K = make_vconst();
@@ -955,7 +963,16 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt,
             __builtin_amdgcn_sched_barrier(0);                                                                     \
             /* two independent streams from here to the end of the pass: */                                        \
             G_NEXT = geometry(K, cur, x, y);                     /* render s+1 (a harmless repeat on the last pass) */ \
-            loss_pixel_scene_any<NL, WITH_GRAD>(K, G_CUR, mi, mt, eps, inv_count, lsum, acc);                      \
+            if (SVBRDF_K3_REMAT_TARGET && NL == 1) {                                                               \
+                unsigned opaque = 0;                                                                               \
+                asm volatile("" : "+v"(opaque));                 /* keeps the reload inside the loop */             \
+                Maps tm;                                                                                           \
+                load_maps_k3(rt.base, rt.plane, rt.pix + opaque, tm);                                              \
+                const MapK mt = prepare<false>(tm);                                                                \
+                loss_pixel_scene_any<NL, WITH_GRAD>(K, G_CUR, mi, mt, eps, inv_count, lsum, acc);                  \
+            } else {                                                                                               \
+                loss_pixel_scene_any<NL, WITH_GRAD>(K, G_CUR, mi, mt_in, eps, inv_count, lsum, acc);               \
+            }                                                                                                      \
         }
         if (SVBRDF_K3_UNROLL2) {
             for (int s = 0;;) {
@@ -978,7 +995,7 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt,
             const Geom g = g_next;
             load_scene(sc_lds + (s + 1 < S ? s + 1 : s) * 9, sc);
             g_next = geometry(K, sc, x, y);
-            loss_pixel_scene_any<NL, WITH_GRAD>(K, g, mi, mt, eps, inv_count, lsum, acc);
+            loss_pixel_scene_any<NL, WITH_GRAD>(K, g, mi, mt_in, eps, inv_count, lsum, acc);
         }
     }
     lsum *= 0.693147180559945309417f;       // the scene loop sums |log2|: natural log once per pixel
@@ -1174,7 +1191,8 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         }
         const float *__restrict__ scp = scenes + (size_t)b * S * 9;
         if (__all(tied))     // wave-uniform: every lane's input AND target roughness channels are tied
-            lsum = loss_scene_loop<1, WITH_GRAD>(mi, mt, x[0], y, scp, sc_lds, S, eps, inv_count, acc);
+            lsum = loss_scene_loop<1, WITH_GRAD>(mi, mt, x[0], y, scp, sc_lds, S, eps, inv_count, acc,
+                                                 RematTarget{target + (size_t)b * 12 * plane, plane, pix});
         else
             lsum = loss_scene_loop<3, WITH_GRAD>(mi, mt, x[0], y, scp, sc_lds, S, eps, inv_count, acc);
         if (WITH_L1) lsum = fma_(l1sum, l1.sum_scale, lsum);
