@@ -17,13 +17,13 @@ T="python3 $R/train.py $EXTRA"
 for cfg in "c2:--batch 8" "c4:--model multi --views 5 --batch 16"; do
   name=${cfg%%:*}; flags=${cfg#*:}
   # 1. cold process (compiles MIOpen's kernels at the first steps), wall time of the whole process recorded
-  SECONDS=0; timeout 1500 $T $flags --steps 6 --warmup 3 > $OUT/${TAG}_train_${name}_cold.json 2> $OUT/${TAG}_train_${name}_cold.err
+  SECONDS=0; timeout 1500 $T $flags --steps 6 --warmup 5 > $OUT/${TAG}_train_${name}_cold.json 2> $OUT/${TAG}_train_${name}_cold.err
   echo "cold process wall seconds: $SECONDS" > $OUT/${TAG}_train_${name}_cold.time
   # 2. warm process: throughput, then phases
-  timeout 600 $T $flags --steps 10 --warmup 3 > $OUT/${TAG}_train_${name}.json 2> $OUT/${TAG}_train_${name}.err
-  timeout 600 $T $flags --steps 6 --warmup 3 --phase-times > $OUT/${TAG}_train_${name}_phases.json 2>> $OUT/${TAG}_train_${name}.err
+  timeout 600 $T $flags --steps 10 --warmup 5 > $OUT/${TAG}_train_${name}.json 2> $OUT/${TAG}_train_${name}.err
+  timeout 600 $T $flags --steps 6 --warmup 5 --phase-times > $OUT/${TAG}_train_${name}_phases.json 2>> $OUT/${TAG}_train_${name}.err
   # 3. kernel trace (dataloader in-process: no forked workers under the profiler)
-  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_train_${name}_prof --output-format csv -- $T $flags --steps 4 --warmup 2 --workers 0 > $OUT/${TAG}_train_${name}_prof.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_train_${name}_prof --output-format csv -- $T $flags --steps 4 --warmup 5 --workers 0 > $OUT/${TAG}_train_${name}_prof.log 2>&1
 done
 ( du -sh $M/db $M/cache; find $M -type f | xargs ls -la ) > $OUT/${TAG}_miopen_cache_size.txt 2>&1
 # the caches travel back only when they are small (gpurun merges at most 64 MiB)

@@ -19,10 +19,10 @@ for spec in "$@"; do
   for cfg in "c2:--batch 8" "c4:--model multi --views 5 --batch 16"; do
     c=${cfg%%:*}; flags=${cfg#*:}
     SECONDS=0
-    env MIOPEN_USER_DB_PATH=$M/db MIOPEN_CUSTOM_CACHE_DIR=$M/cache $envs timeout 900 python3 $R/train.py $flags --conv-mode $m $extra --steps 6 --warmup 3 --workers 0 \
+    env MIOPEN_USER_DB_PATH=$M/db MIOPEN_CUSTOM_CACHE_DIR=$M/cache $envs timeout 900 python3 $R/train.py $flags --conv-mode $m $extra --steps 6 --warmup 5 --workers 0 \
         > $OUT/${TAG}_mode_${name}_${c}_cold.json 2> $OUT/${TAG}_mode_${name}_${c}.err
     echo "{\"cold_process_wall_s\": $SECONDS}" >> $OUT/${TAG}_mode_${name}_${c}_cold.json
-    env MIOPEN_USER_DB_PATH=$M/db MIOPEN_CUSTOM_CACHE_DIR=$M/cache $envs timeout 600 python3 $R/train.py $flags --conv-mode $m $extra --steps 10 --warmup 3 --workers 0 --phase-times \
+    env MIOPEN_USER_DB_PATH=$M/db MIOPEN_CUSTOM_CACHE_DIR=$M/cache $envs timeout 600 python3 $R/train.py $flags --conv-mode $m $extra --steps 10 --warmup 5 --workers 0 --phase-times \
         > $OUT/${TAG}_mode_${name}_${c}.json 2>> $OUT/${TAG}_mode_${name}_${c}.err
     echo "$spec $c: $(tail -n 1 $OUT/${TAG}_mode_${name}_${c}.json | cut -c1-330) cold ${SECONDS}s"
   done

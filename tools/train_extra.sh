@@ -17,9 +17,9 @@ for w in 2 8 16; do
 done
 timeout 900 python3 train.py --data /tmp/pngds --image-count 1 --random-crop --batch 8 --steps 60 --warmup 10 --workers 16 > $OUT/${TAG}_train_c3_png.json 2>> $OUT/${TAG}_train_c3_png_w16.err
 SECONDS=0
-timeout 1500 python3 train.py --size 512 --random-scenes 11 --specular-scenes 21 --batch 8 --steps 6 --warmup 3 > $OUT/${TAG}_train_c5_cold.json 2> $OUT/${TAG}_train_c5.err
+timeout 1500 python3 train.py --size 512 --random-scenes 11 --specular-scenes 21 --batch 8 --steps 6 --warmup 5 > $OUT/${TAG}_train_c5_cold.json 2> $OUT/${TAG}_train_c5.err
 echo "{\"cold_process_wall_s\": $SECONDS}" >> $OUT/${TAG}_train_c5_cold.json
-timeout 900 python3 train.py --size 512 --random-scenes 11 --specular-scenes 21 --batch 8 --steps 10 --warmup 3 --phase-times > $OUT/${TAG}_train_c5.json 2>> $OUT/${TAG}_train_c5.err
+timeout 900 python3 train.py --size 512 --random-scenes 11 --specular-scenes 21 --batch 8 --steps 10 --warmup 5 --phase-times > $OUT/${TAG}_train_c5.json 2>> $OUT/${TAG}_train_c5.err
 tail -n 1 $OUT/${TAG}_train_c5.json | cut -c1-700
 timeout 900 python3 train.py --fused-head --batch 8 --steps 20 --warmup 5 --phase-times > $OUT/${TAG}_train_c2_fused_head.json 2> $OUT/${TAG}_train_c2_fused_head.err
 tail -n 1 $OUT/${TAG}_train_c2_fused_head.json | cut -c1-700

@@ -54,7 +54,7 @@ def parse_args(argv=None):
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--lr", type=float, default=1e-5)                    # main.py:74
     ap.add_argument("--l1-weight", type=float, default=0.1)              # losses.py:55
     ap.add_argument("--random-scenes", type=int, default=3)              # losses.py:26
@@ -74,17 +74,18 @@ def parse_args(argv=None):
     ap.add_argument("--resume", default=None,
                     help="checkpoint to start from: one written by --save, or a checkpoint.tar of the reference "
                          "(persistence.py:52-69; model weights only)")
-    ap.add_argument("--conv-mode", choices=("hybrid", "reference", "fast", "autotune"), default="hybrid",
+    ap.add_argument("--conv-mode", choices=("auto", "hybrid", "reference", "fast", "autotune"), default="auto",
                     help="how stock PyTorch-ROCm picks the U-Net's MIOpen convolution algorithms (DESIGN.md section 10).  "
-                         "reference: cudnn.deterministic=True, benchmark=False as utils.py:11-12 sets them -- on ROCm that "
-                         "pins EVERY convolution, forward and backward, to MIOpen's im2col+GEMM algorithm, one GEMM per "
-                         "image: fine forward, pathological backward (2.7 s per step at configs[3]); fast: "
-                         "deterministic=False, benchmark=False -- MIOpen's immediate-mode heuristic choice, no search: good "
-                         "backward, 5x slower forward; hybrid (default): the reference's setting while the network runs "
-                         "forward (same algorithms, same bits as the reference setting), the immediate-mode choice while "
-                         "autograd runs backward -- the flags are read when a convolution executes; autotune: "
-                         "benchmark=True -- MIOpen's find step compiles and times the candidates at the first call of "
-                         "every shape (7 min at config 2, > 15 min at configs[3] on a fresh box)")
+                         "reference: cudnn.deterministic=True, benchmark=False as utils.py:11-12 sets them -- on ROCm a fine "
+                         "forward and a pathological backward (2.7 s per step at configs[3]); fast: deterministic=False, "
+                         "benchmark=False -- MIOpen's immediate-mode choice, no search: good backward; its forward is 5x "
+                         "slower than the reference-flag forward on a box without stored find results and 30 %% faster with "
+                         "them; hybrid: the reference's flags while the network runs forward, the immediate-mode choice while "
+                         "autograd runs backward (the flags are read when a convolution executes); auto (default): hybrid, "
+                         "plus a calibration during the first four steps that times the forward under both settings and "
+                         "keeps the faster one -- no search, right on a fresh box and on one with a tuned cache; autotune: "
+                         "benchmark=True -- MIOpen's find step compiles and times every candidate at the first call of "
+                         "each shape (7 min at config 2; > 44 min at configs[3]); its results land in MIOpen's user cache")
     ap.add_argument("--autotune", action="store_true", help="same as --conv-mode autotune")
     ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights for the U-Net")
     ap.add_argument("--share-device", action="store_true",
@@ -166,7 +167,11 @@ def run(args):
     if conv_mode in ("fast", "autotune"):       # enable_deterministic_random_engine set the reference's flags above
         torch.backends.cudnn.deterministic = False
         torch.backends.cudnn.benchmark = conv_mode == "autotune"
-    hybrid = conv_mode == "hybrid" and on_gpu
+    hybrid = conv_mode in ("hybrid", "auto") and on_gpu
+    auto = conv_mode == "auto" and on_gpu
+    # auto: forward under the reference's flags at steps 0-1, under the immediate-mode choice at steps 2-3 (the first of
+    # each pair compiles, the second is timed with HIP events); from step 4 on the faster of the two
+    forward_flag, calib = True, {}
     steps_done = 0
     if args.resume:
         ck = torch.load(args.resume, map_location="cpu", weights_only=False)
@@ -273,8 +278,20 @@ def run(args):
         optimizer.zero_grad(set_to_none=True)
         if timing:
             marks.append(mark())
+        if auto:
+            if step < 4:
+                forward_flag = step < 2
+            elif step == 4 and len(calib) == 2:
+                forward_flag = calib[True] <= calib[False]
+            probe = (mark(), None) if step in (1, 3) else None
+        if hybrid:
+            torch.backends.cudnn.deterministic = forward_flag
         out = model(net_in)
-        if hybrid:      # forward ran under the reference's flags (im2col+GEMM); backward takes MIOpen's immediate-mode choice
+        if auto and probe is not None:
+            probe = (probe[0], mark())
+            torch.cuda.synchronize(dev)
+            calib[forward_flag] = probe[0].elapsed_time(probe[1])
+        if hybrid:      # backward always takes MIOpen's immediate-mode choice
             torch.backends.cudnn.deterministic = False
         if timing:
             marks.append(mark())
@@ -332,6 +349,9 @@ def run(args):
                          "data": ("synthetic (device)" if device_source else args.data) if args.data.startswith("synthetic") else "tiled-png",
                          "workers": args.workers, "conv_mode": conv_mode, "channels_last": bool(args.channels_last),
                          "miopen_cache": "in-tree" if miopen_cache else "the user's / MIOpen's default"}}
+    if auto:
+        result["config"]["conv_forward"] = {"chosen": "reference flags" if forward_flag else "immediate mode",
+                                            "calibration_ms": {("reference flags" if k else "immediate mode"): v for k, v in calib.items()}}
     if timing:
         result["phase_ms_mean"] = {k: sum(v) / max(1, len(v)) for k, v in phase_ms.items()}
         result["phase_note"] = "per-step means over the timed steps; one device synchronisation per step (not a throughput run)"
