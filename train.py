@@ -17,6 +17,13 @@ batch -> (synthesise missing photos) -> model -> MixedLoss -> backward -> Adam(l
   python train.py --size 512 --random-scenes 11 --specular-scenes 21   # BASELINE config 5 (per GPU)
   python train.py --data /path/to/tiled_pngs --image-count 10  # Deschaintre tiled-PNG samples
 
+  python train.py --gpus 1 --force-dist                        # one GPU, but every multi-rank branch (RCCL process group, DDP)
+  python train.py --gpus 2 --backend gloo --share-device       # two ranks on one GPU (control flow of an N-GPU run)
+
+Convolutions: the U-Net runs on stock PyTorch-ROCm (MIOpen).  ``--conv-mode auto`` (default) picks, per direction, between
+the reference's cudnn flags and MIOpen's immediate-mode choice (a four-step calibration of the forward; backward always
+immediate: the reference's ``deterministic=True`` pins MIOpen to a backward 5-20x slower) -- DESIGN.md section 10.
+
 Prints one JSON line per run on rank 0 (end-to-end patches/s, mean loss of the first/last steps).
 """
 import argparse
