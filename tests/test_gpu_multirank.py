@@ -105,5 +105,7 @@ def test_ddp_fused_loss_two_ranks_equal_the_global_batch(tmp_path):
     gmax = np.abs(a["grad"]).max()
     err = np.abs(a["grad"] - b["grad"]).max()
     print("DDP (2 ranks) vs global batch: loss %.7f / %.7f, gradient max err / max = %.2e" % (a["loss"], b["loss"], err / gmax))
-    # the convolutions' weight gradients sum over the batch in a different order (2 + 2 averaged vs 4), nothing else differs
-    assert np.isfinite(a["grad"]).all() and gmax > 0 and err <= 1e-4 * gmax
+    # the convolutions' weight gradients sum over the batch in a different order (2 + 2 averaged vs 4) and MIOpen picks its
+    # algorithms per batch shape; nothing else differs.  Measured 6.0e-5 ... 6.8e-5 of max over the boxes and conv modes of
+    # round 3 (fp32 convolutions over 65,536 pixels); a sharding or scene-stream mistake is O(1) of max
+    assert np.isfinite(a["grad"]).all() and gmax > 0 and err <= 3e-4 * gmax
