@@ -475,6 +475,10 @@ struct RenderBackward : public torch::autograd::Node {
         TORCH_CHECK(m.defined(), "Trying to backward through LocalRenderer.render a second time: the saved maps were freed; "
                                  "specify retain_graph=True for the first backward");
         at::AutoDispatchBelowADInplaceOrView below_autograd;
+        if (!grads[0].defined()) {               // an undefined cotangent means zeros
+            out[0] = at::zeros_like(m);
+            return out;
+        }
         const auto go = grads[0].contiguous();
         TORCH_CHECK(go.scalar_type() == at::kFloat && go.numel() == (int64_t)B * S * 3 * H * W, "render backward: bad cotangent");
         auto grad = at::empty_like(m);

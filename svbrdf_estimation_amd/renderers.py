@@ -26,16 +26,21 @@ class _RenderFunction(torch.autograd.Function):
     def forward(ctx, maps, scenes):
         if not maps.is_contiguous():
             maps = maps.contiguous()
-        ctx.save_for_backward(maps)
-        ctx.scenes = scenes                     # not a graph tensor: kept as a plain attribute
+        if scenes.is_cuda:
+            ctx.save_for_backward(maps, scenes)                    # version-checked like any saved tensor
+            ctx.host_scenes = None
+        else:
+            ctx.save_for_backward(maps)
+            ctx.host_scenes = scenes.detach().clone()              # a few rows: the caller may reuse its buffer
         return _native.render_fwd(maps, scenes)
 
     @staticmethod
     def backward(ctx, grad_out):
         if not ctx.needs_input_grad[0]:
             return None, None
-        maps, = ctx.saved_tensors
-        return _native.render_bwd(maps, ctx.scenes, grad_out), None
+        saved = ctx.saved_tensors
+        scenes = ctx.host_scenes if ctx.host_scenes is not None else saved[1]
+        return _native.render_bwd(saved[0], scenes, grad_out), None
 
 
 class LocalRenderer:
