@@ -62,16 +62,25 @@ class TiledPngDataset(torch.utils.data.Dataset):
                     and ``apply_mixing`` blends at that resolution and resizes afterwards, in the reference's order.
     ``no_svbrdf``   photos only: a flat dummy SVBRDF (normals (0,0,1), everything else 0), dataset.py:116-124.
 
+    ``uint8_transport`` ('crop' mode): items hold the cropped 8-bit pixels ('inputs_u8' [n,3,S,S], 'svbrdf_u8' [12,S,S],
+                    'svbrdf_other_u8') instead of decoded floats; ``decode_uint8_batch`` turns a collated batch into
+                    exactly the tensors of the float path, on whatever device it is given.  Same RNG draws, same order.
+
     Returns {'inputs': [n,3,S,S], 'svbrdf': [12,S,S]} (+ 'svbrdf_other', 'mix_alpha' when mixing)."""
 
     def __init__(self, directory, image_size=256, image_count=10, used_image_count=1, is_linear=False, scale_mode="crop",
-                 random_crop=False, mix_materials=False, no_svbrdf=False):
+                 random_crop=False, mix_materials=False, no_svbrdf=False, uint8_transport=False):
         self.paths = sorted(os.path.join(directory, f) for f in os.listdir(directory)
                             if os.path.isfile(os.path.join(directory, f)))
         if scale_mode not in ("crop", "resize"):
             raise ValueError("Unknown scale mode {}".format(scale_mode))
         self.image_size, self.image_count, self.used, self.is_linear = image_size, image_count, used_image_count, is_linear
         self.scale_mode, self.random_crop, self.no_svbrdf = scale_mode, random_crop, no_svbrdf
+        # uint8_transport: hand the cropped 8-bit pixels to the training process and decode them THERE, on the device
+        # (decode_uint8_batch: three 256-entry lookup tables built with the reference's CPU arithmetic, so the decoded
+        # tensors are bit for bit what this reader returns otherwise) -- a quarter of the bytes through the worker ->
+        # pinned-memory -> device pipeline and no float conversion in the workers.  'crop' mode only (a resize needs floats).
+        self.uint8_transport = bool(uint8_transport) and scale_mode == "crop" and not no_svbrdf
         self.mix_materials = mix_materials
         if self.mix_materials and self.image_count > 0:
             self.mix_materials = False
@@ -121,7 +130,39 @@ class TiledPngDataset(torch.utils.data.Dataset):
             svbrdfs = [_crop_square(m, anchor, S) for m in svbrdfs]
         return photos, svbrdfs
 
+    def _read_tiles_u8(self, path):
+        """-> uint8 [tiles,3,H,W]: the sample's tiles as stored (photos, then normals | diffuse | roughness | specular)"""
+        from PIL import Image
+        img = torch.from_numpy(np.array(Image.open(path).convert("RGB"))).permute(2, 0, 1)       # [3,H,tiles*W] uint8
+        tiles = self.image_count + 4
+        if img.shape[-1] % tiles != 0:
+            raise ValueError("%s: width %d is not %d equal tiles" % (path, img.shape[-1], tiles))
+        return torch.stack(img.chunk(tiles, dim=-1), dim=0)
+
+    def _getitem_u8(self, idx):
+        """the 'crop' path on 8-bit pixels: same draws in the same order as __getitem__ (partner, weight, anchor)"""
+        tiles = self._read_tiles_u8(self.paths[idx])
+        other, alpha = None, None
+        if self.mix_materials:
+            import random
+            other = self._read_tiles_u8(self.paths[random.randrange(0, len(self))])     # dataset.py:54
+            alpha = synthesis.draw_mix_alpha()                                          # dataset.py:144
+        height, width = tiles.shape[-2:]
+        S = self.image_size
+        anchor = (0, 0)
+        if self.random_crop:
+            anchor = (np.random.randint(0, height - S + 1), np.random.randint(0, width - S + 1))
+        keep = min(self.image_count, self.used)
+        n = self.image_count
+        crop = lambda t: _crop_square(t, anchor, S).contiguous()
+        item = {"inputs_u8": crop(tiles[n - keep:n]), "svbrdf_u8": crop(tiles[n:n + 4]).reshape(12, S, S)}
+        if other is not None:
+            item["svbrdf_other_u8"], item["mix_alpha"] = crop(other[n:n + 4]).reshape(12, S, S), alpha
+        return item
+
     def __getitem__(self, idx):
+        if self.uint8_transport:
+            return self._getitem_u8(idx)
         photos, svbrdf = self.read_sample(self.paths[idx])
         maps, alpha = [svbrdf], None
         if self.mix_materials:
@@ -139,6 +180,38 @@ class TiledPngDataset(torch.utils.data.Dataset):
             if blend_first:
                 item["resize_to"] = self.image_size
         return item
+
+
+_LUTS = {}
+
+
+def _decode_luts(device):
+    """three 256-entry tables, computed ONCE on the CPU with the float path's own operations -- value / 255 as
+    ``read_tiled_png`` forms it, ``* 2 - 1`` for normals (utils.decode_from_unit_interval), ``pow(2.2)`` for stored photos
+    (utils.gamma_decode) -- so that a gather on any device reproduces the float path bit for bit"""
+    key = str(device)
+    if key not in _LUTS:
+        unit = torch.from_numpy(np.arange(256, dtype=np.uint8).astype(np.float32) / 255.0)
+        _LUTS[key] = tuple(t.to(device) for t in (unit, utils.decode_from_unit_interval(unit), utils.gamma_decode(unit)))
+    return _LUTS[key]
+
+
+def decode_uint8_batch(batch, device, is_linear=False):
+    """collated batch of a ``uint8_transport`` dataset -> the batch the float path would have produced, on `device`:
+    {'inputs' [B,n,3,S,S], 'svbrdf' [B,12,S,S]} (+ 'svbrdf_other', 'mix_alpha').  A float batch passes through."""
+    if "svbrdf_u8" not in batch:
+        return batch
+    unit, normals, gamma = _decode_luts(torch.device(device))
+
+    def maps(u8):
+        idx = u8.to(device, non_blocking=True).long()
+        return torch.cat((normals[idx[:, 0:3]], unit[idx[:, 3:12]]), dim=1)
+
+    photos = batch["inputs_u8"].to(device, non_blocking=True).long()
+    out = {"inputs": (unit if is_linear else gamma)[photos], "svbrdf": maps(batch["svbrdf_u8"])}
+    if "svbrdf_other_u8" in batch:
+        out["svbrdf_other"], out["mix_alpha"] = maps(batch["svbrdf_other_u8"]), batch["mix_alpha"]
+    return out
 
 
 def apply_mixing(batch_svbrdf, batch):

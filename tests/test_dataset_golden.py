@@ -109,6 +109,41 @@ def test_mixing_with_resize_blends_before_it_resizes_like_the_reference(tmp_path
     assert batch["resize_to"].tolist() == [20, 20] and tuple(batch["svbrdf"].shape) == (2, 12, 28, 28)
 
 
+def test_uint8_transport_decodes_to_the_float_path_bit_for_bit(tmp_path, golden):
+    """`uint8_transport=True`: the workers ship cropped 8-bit pixels, `decode_uint8_batch` gathers three 256-entry tables
+    built with the float path's own CPU arithmetic -- the decoded batch must BE the float path's batch (photos incl. gamma
+    decode, normals * 2 - 1, maps), with the same numpy / python / torch RNG draws in the same order (random crop, mixing
+    partner, blend weight)."""
+    from svbrdf_estimation_amd.training import data
+    for files, kw in ((["g12_tiled_synthetic.png"], dict(image_size=32, image_count=3, used_image_count=2, random_crop=True)),
+                      (["g12_tiled_toy_crop.png"], dict(image_size=32, image_count=10, used_image_count=1)),
+                      (["g12_tiled_toy_crop.png"], dict(image_size=32, image_count=10, used_image_count=3, is_linear=True, random_crop=True)),
+                      (["g12_maps_only_0.png", "g12_maps_only_1.png"], dict(image_size=24, image_count=0, used_image_count=0,
+                                                                             mix_materials=True, random_crop=True))):
+        sub = tmp_path / ("u8_%d" % len(list(tmp_path.iterdir())))
+        sub.mkdir()
+        a = _dataset(sub, files, scale_mode="crop", **kw)
+        b = data.TiledPngDataset(str(sub / "ds"), scale_mode="crop", uint8_transport=True, **kw)
+        assert b.uint8_transport
+        states, batches = [], []
+        for ds in (a, b):
+            random.seed(4)
+            np.random.seed(5)
+            torch.manual_seed(6)
+            items = [ds[i % len(ds)] for i in range(3)]
+            states.append((random.random(), np.random.rand(), torch.get_rng_state()))
+            batches.append(torch.utils.data.default_collate(items))
+        assert states[0][0] == states[1][0] and states[0][1] == states[1][1] and torch.equal(states[0][2], states[1][2])
+        assert batches[1]["svbrdf_u8"].dtype == torch.uint8
+        dec = data.decode_uint8_batch(batches[1], "cpu", is_linear=kw.get("is_linear", False))
+        assert set(dec) == set(batches[0])
+        for k in batches[0]:
+            assert torch.equal(dec[k], batches[0][k]), (files, k)
+    # a float batch passes through untouched; 'resize' keeps the float path
+    assert data.decode_uint8_batch(batches[0], "cpu") is batches[0]
+    assert not data.TiledPngDataset(str(sub / "ds"), scale_mode="resize", uint8_transport=True, image_count=0).uint8_transport
+
+
 def _mix_restated(a, b, alpha):
     n0, n1 = a[0:3] / torch.max(torch.tensor([0.01]), a[2:3]), b[0:3] / torch.max(torch.tensor([0.01]), b[2:3])
     n = alpha * n0 + (1.0 - alpha) * n1

@@ -1106,6 +1106,24 @@ def test_mixing_dataset_with_resize_through_the_gpu(dev, golden, tmp_path):
         assert err <= 5e-7, (idx, err)
 
 
+def test_uint8_transport_decoded_on_the_device_equals_the_float_reader(dev, tmp_path):
+    """the 8-bit transport of the tiled-PNG reader: lookup-table decode ON THE DEVICE == the float path of the reader
+    (which is pinned bit for bit against the reference's SvbrdfDataset), photos with gamma decode, normals, maps"""
+    import shutil
+    from svbrdf_estimation_amd.training import data
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    shutil.copy(os.path.join(gdir, "g12_tiled_toy_crop.png"), str(tmp_path))
+    kw = dict(image_size=48, image_count=10, used_image_count=2, random_crop=True)
+    a = data.TiledPngDataset(str(tmp_path), **kw)
+    b = data.TiledPngDataset(str(tmp_path), uint8_transport=True, **kw)
+    np.random.seed(11)
+    fa = torch.utils.data.default_collate([a[0], a[0]])
+    np.random.seed(11)
+    fb = data.decode_uint8_batch(torch.utils.data.default_collate([b[0], b[0]]), dev)
+    assert fb["inputs"].is_cuda and fb["inputs"].dtype == torch.float32
+    assert torch.equal(fb["inputs"].cpu(), fa["inputs"]) and torch.equal(fb["svbrdf"].cpu(), fa["svbrdf"])
+
+
 @pytest.mark.parametrize("tag", ["single", "multi"])
 def test_unet_forward_equals_reference_fixture_on_the_gpu(dev, golden, tag):
     """the re-stated network on the MIOpen path against the reference's forward pass (regenerated weights, fixture

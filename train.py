@@ -74,6 +74,12 @@ def parse_args(argv=None):
                     help="DataLoader worker processes per rank; -1 = from the host: (cpus / ranks on this node) - 1, at "
                          "least 2, at most 16 -- the tiled-PNG reader delivers ~45-60 samples/s per worker "
                          "(tools/loader_rate.py), a training step consumes hundreds per GPU")
+    ap.add_argument("--float-transport", action="store_true",
+                    help="tiled-PNG samples: decode to float32 in the DataLoader workers (the reference's way) instead of "
+                         "shipping the cropped 8-bit pixels and decoding them on the device with lookup tables (same bits, a "
+                         "quarter of the bytes; 'crop' scale mode only)")
+    ap.add_argument("--no-pin", action="store_true", help="DataLoader without the pinned-memory staging thread")
+    ap.add_argument("--prefetch", type=int, default=4, help="batches each DataLoader worker keeps ready (prefetch_factor)")
     ap.add_argument("--seed", type=int, default=313)                     # utils.py:7
     ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"))
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl on cuda, gloo on cpu)")
@@ -226,7 +232,7 @@ def run(args):
         dataset = data.TiledPngDataset(args.data, image_size=args.size, image_count=args.image_count,
                                        used_image_count=args.views, is_linear=args.linear_input,
                                        scale_mode=args.scale_mode, random_crop=args.random_crop,
-                                       mix_materials=args.mix_materials)
+                                       mix_materials=args.mix_materials, uint8_transport=on_gpu and not args.float_transport)
     if device_source:
         sampler = loader = None
     elif verify:
@@ -236,8 +242,9 @@ def run(args):
                                                                   seed=args.seed, drop_last=True) if world > 1 else None
     if not device_source:
         loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch, sampler=sampler, shuffle=sampler is None,
-                                             num_workers=args.workers, pin_memory=on_gpu, drop_last=True,
-                                             persistent_workers=args.workers > 0)
+                                             num_workers=args.workers, pin_memory=on_gpu and not args.no_pin, drop_last=True,
+                                             persistent_workers=args.workers > 0,
+                                             **({"prefetch_factor": args.prefetch} if args.workers > 0 else {}))
 
     def batches():
         if device_source:
@@ -274,6 +281,7 @@ def run(args):
         batch = next(it)
         t_wait = time.perf_counter() - t_wait
         marks = [mark()] if timing else None
+        batch = data.decode_uint8_batch(batch, dev, is_linear=args.linear_input)    # 8-bit transport: decoded on the device
         svbrdf = batch["svbrdf"].to(dev, non_blocking=True)
         stored = batch["inputs"].to(dev, non_blocking=True)
         if on_gpu and not verify:
