@@ -188,7 +188,9 @@ _LUTS = {}
 def _decode_luts(device):
     """three 256-entry tables, computed ONCE on the CPU with the float path's own operations -- value / 255 as
     ``read_tiled_png`` forms it, ``* 2 - 1`` for normals (utils.decode_from_unit_interval), ``pow(2.2)`` for stored photos
-    (utils.gamma_decode) -- so that a gather on any device reproduces the float path bit for bit"""
+    (utils.gamma_decode) -- so that a gather on any device reproduces the float path: exactly for the maps (IEEE division
+    and multiply-add of 256 values), and for the photos up to the last bit of torch's CPU ``pow`` (not correctly rounded:
+    its vectorised and scalar code paths can differ by 1 ULP on some hosts; identical in the build container)"""
     key = str(device)
     if key not in _LUTS:
         unit = torch.from_numpy(np.arange(256, dtype=np.uint8).astype(np.float32) / 255.0)

@@ -1121,7 +1121,12 @@ def test_uint8_transport_decoded_on_the_device_equals_the_float_reader(dev, tmp_
     np.random.seed(11)
     fb = data.decode_uint8_batch(torch.utils.data.default_collate([b[0], b[0]]), dev)
     assert fb["inputs"].is_cuda and fb["inputs"].dtype == torch.float32
-    assert torch.equal(fb["inputs"].cpu(), fa["inputs"]) and torch.equal(fb["svbrdf"].cpu(), fa["svbrdf"])
+    assert torch.equal(fb["svbrdf"].cpu(), fa["svbrdf"])                     # value / 255 and * 2 - 1: exact arithmetic
+    # the photos go through pow(x, 2.2), which torch's CPU kernels do not round correctly and not identically on their
+    # vectorised and scalar paths: the 256-entry table (contiguous) and the reader's strided crop may differ in the last bit
+    # on some hosts (they are equal, bit for bit, in the build container: tests/test_dataset_golden.py)
+    err = (fb["inputs"].cpu() - fa["inputs"]).abs()
+    assert (err <= 2.4e-7 * fa["inputs"].abs() + 1e-12).all(), err.max()
 
 
 @pytest.mark.parametrize("tag", ["single", "multi"])
