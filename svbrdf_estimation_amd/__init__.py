@@ -25,7 +25,7 @@ __all__ = ["environment", "losses", "renderers", "synthesis", "utils", "distribu
 _PATCHED = {"renderers": ("LocalRenderer",), "losses": ("SVBRDFL1Loss", "RenderingLoss", "MixedLoss")}
 
 
-def install(modules=None):
+def install(modules=None, patch_renderer=True):
     """make the REFERENCE'S OWN flat modules hand out this engine's hot-path classes,
     without editing its files.  Call it once, before the training script's ``from losses import MixedLoss`` /
     ``from renderers import LocalRenderer`` run (top of main.py, or a sitecustomize):
@@ -36,11 +36,18 @@ def install(modules=None):
     is on sys.path) and rebinds ``LocalRenderer`` / ``SVBRDFL1Loss`` / ``RenderingLoss`` / ``MixedLoss`` in them;
     everything else in those modules (RednerRenderer, OrthoToPerspectiveMapping, ...) and the reference's
     ``environment`` / ``utils`` / ``dataset`` / ``models`` stay the reference's.  ``modules`` (for tests): a dict
-    {"renderers": module, "losses": module} to patch instead of importing by name.  Returns what it replaced."""
+    {"renderers": module, "losses": module} to patch instead of importing by name.  Returns what it replaced.
+
+    ``patch_renderer=False`` leaves ``renderers.LocalRenderer`` the reference's: its CPU dataloader renders missing input
+    photos with it in the worker processes (dataset.py:206-212), where this engine has nothing to offer (no CPU path),
+    while the patched ``RenderingLoss`` / ``MixedLoss`` still take the fused kernel -- they recognise the reference's
+    ``LocalRenderer`` object as the renderer the kernels replace (``losses.RenderingLoss.uses_fused_kernel``)."""
     import importlib
     mine = {"renderers": renderers, "losses": losses}
     replaced = {}
     for mname, names in _PATCHED.items():
+        if mname == "renderers" and not patch_renderer:
+            continue
         target = modules[mname] if modules is not None else importlib.import_module(mname)
         if target is mine[mname]:
             continue

@@ -399,6 +399,15 @@ loss_function = MixedLoss(LocalRenderer())            # main.py:82-89
 assert loss_function.rendering_loss.uses_fused_kernel() and loss_function.l1_weight == 0.1
 import dataset                                        # dataset.py:7 `import renderers` -> :206 renderers.LocalRenderer()
 assert dataset.renderers.LocalRenderer is LocalRenderer
+# patch_renderer=False: the reference keeps ITS LocalRenderer (CPU dataloader workers), the losses still fuse
+renderers.LocalRenderer = replaced["renderers.LocalRenderer"]
+amd.install(patch_renderer=False)
+assert renderers.LocalRenderer.__module__ == "renderers" and renderers.LocalRenderer is not amd.renderers.LocalRenderer
+assert losses.MixedLoss is amd.losses.MixedLoss
+assert losses.MixedLoss(renderers.LocalRenderer()).rendering_loss.uses_fused_kernel()
+class Tracer(renderers.LocalRenderer):                # a subclass that may override render() is a plugin, not the kernel
+    pass
+assert not losses.RenderingLoss(Tracer()).uses_fused_kernel() and not losses.RenderingLoss(object()).uses_fused_kernel()
 print("INSTALL-OK")
 """ % (_REFERENCE, ROOT, _REFERENCE, _REFERENCE)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
