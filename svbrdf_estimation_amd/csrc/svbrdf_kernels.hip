@@ -55,7 +55,10 @@
 namespace {
 
 constexpr int kThreads = 256;          // 4 waves of 64 (K1, K2)
-constexpr int kLossThreads = 256;      // K3 workgroup; 64 and 128 threads measured no faster
+#ifndef SVBRDF_K3_THREADS
+#define SVBRDF_K3_THREADS 256
+#endif
+constexpr int kLossThreads = SVBRDF_K3_THREADS;      // K3 workgroup of the unsplit layout (64 / 128: A/B builds)
 constexpr float kPi = 3.14159274101257324219f;  // float32(math.pi), renderers.py:20,27
 constexpr float kMinDot = 0.001f;      // renderers.py:48-52
 constexpr float kMinRough = 0.001f;    // renderers.py:87
@@ -107,6 +110,9 @@ __device__ __forceinline__ float log2_(float x) { return SVBRDF_ABLATE == 8 ? x 
 #endif
 #ifndef SVBRDF_K3_UNROLL2
 #define SVBRDF_K3_UNROLL2 1        // scene loop of the forward+adjoint kernels: two passes per trip, geometry ping-pong
+#endif
+#ifndef SVBRDF_K3_PEEL_LAST
+#define SVBRDF_K3_PEEL_LAST 0      // 1: the last render of a wave is shaded without the (unused) geometry of a successor
 #endif
 #ifndef SVBRDF_K3_MIN_WAVES
 #define SVBRDF_K3_MIN_WAVES 4      // waves/SIMD the register allocator must leave room for (128 VGPRs)
@@ -471,6 +477,13 @@ __device__ __forceinline__ void store_grads(float *__restrict__ base, size_t pla
 #ifndef SVBRDF_K3_ADDR32
 #define SVBRDF_K3_ADDR32 1
 #endif
+#ifndef SVBRDF_K3_STORE_AUX
+// Cache policy of K3's gradient stores: sc0 sc1 = write-through.  A launch cannot end before its dirty lines have left
+// the eight XCDs' L2s; with plain stores the 25 MB of gradients of config 2 pile up there and the release at the end of
+// the kernel costs ~1.4 us (same-box A/B, profiles/r04_ab_micro.txt: 38.2 -> 36.8 us per launch one at a time, equal
+// with two launches in flight; nt alone gains 1.1).  A/B builds: 0 = plain, 2 = nt, 17 = sc0 sc1, 19 = all three.
+#define SVBRDF_K3_STORE_AUX 17
+#endif
 struct PlaneBuf {
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned lane_bytes;        // pixel index * 4
@@ -491,7 +504,8 @@ __device__ __forceinline__ float plane_load(const PlaneBuf &p, int k)
 }
 __device__ __forceinline__ void plane_store(const PlaneBuf &p, int k, float v)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), p.rsrc, p.lane_bytes, k * p.plane_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), p.rsrc, p.lane_bytes, k * p.plane_bytes,
+                                          SVBRDF_K3_STORE_AUX);
 }
 
 __device__ __forceinline__ void load_maps_k3(const float *__restrict__ base, size_t plane, size_t pix, Maps &m)
@@ -527,6 +541,20 @@ __device__ __forceinline__ void store_grads_k3(float *__restrict__ base, size_t 
         plane_store(p, 6 + k, g.r[k]);
         plane_store(p, 9 + k, g.s[k]);
     }
+}
+
+// With the L1 terms behind a wave-uniform branch (scene-split workgroups: wave 0 only), the compiler re-issues the plane
+// loads inside the branch instead of keeping the values (loads from __restrict__ const memory are rematerialisable), each
+// followed by its own s_waitcnt: the prologue then serialises a dozen memory latencies.  An empty asm that "modifies"
+// the loaded value makes it an ordinary register value.
+__device__ __forceinline__ void pin_loaded(float *v, int n)
+{
+#pragma unroll
+    for (int i = 0; i < n; ++i) asm volatile("" : "+v"(v[i]));
+}
+__device__ __forceinline__ void pin_maps(Maps &m)
+{
+    pin_loaded(m.n, 3); pin_loaded(m.d, 3); pin_loaded(m.r, 3); pin_loaded(m.s, 3);
 }
 
 __device__ __forceinline__ void zero_grad(Grad &g)
@@ -762,6 +790,9 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 constexpr int kLossSlots = 64;                    // sharded accumulators (power of two)
+#ifndef SVBRDF_K3_SPLIT_VARIANTS
+#define SVBRDF_K3_SPLIT_VARIANTS 0                // 1: also build the scene-split workgroup layouts (experiment, see below)
+#endif
 constexpr int kLossCountShift = 48;               // word = arrivals << 48 | fixed-point sum
 constexpr unsigned long long kLossSumMask = (1ULL << kLossCountShift) - 1;
 constexpr unsigned long long kLossTicketMask = 0xffffffffULL;   // ws[kLossSlots]: low half counts slot completions,
@@ -925,6 +956,33 @@ __device__ __forceinline__ void loss_pixel_scene_any(const VConst &K, const Geom
 // The adjoint kernel sits at the 128-VGPR limit of 4 waves/SIMD and spills a little either way; the
 // LDS variant keeps the scalars live across the interleaved streams and spills more.  So: LDS for
 // the forward-only kernels, prefetched global loads for the forward+adjoint kernels.
+// Issue priority in the tail of a launch (experiment, default off).  The SIMD arbitrates by user priority first, age
+// second.  By age alone the oldest wave of a SIMD runs at its lone speed and the youngest gets the leftovers, so the last
+// four waves of every SIMD finish one by one ~3 us apart and the very last runs alone for ~3.5 us at half the SIMD's
+// issue rate (tools/k3_timeline.py).  SVBRDF_K3_TAIL_PRIO = 1: waves of the LAST resident round (workgroups
+// >= nblocks - SVBRDF_K3_CAPACITY) take priority 2 / 1 / 0 by the third of their renders they are in (more remaining =
+// higher), all earlier waves priority 3: the last round's waves converge and finish together, nothing else changes.
+// = 2: every wave by remaining work (round 1's experiment: the rounds then start in lockstep).
+#ifndef SVBRDF_K3_TAIL_PRIO
+#define SVBRDF_K3_TAIL_PRIO 0
+#endif
+#ifndef SVBRDF_K3_STAGGER
+#define SVBRDF_K3_STAGGER 0
+#endif
+#ifndef SVBRDF_K3_EARLY_COORDS
+#define SVBRDF_K3_EARLY_COORDS 1    // pixel coordinates loaded in front of the plane loads (rendering_loss_body)
+#endif
+#ifndef SVBRDF_K3_CAPACITY
+#define SVBRDF_K3_CAPACITY 1024     // resident 256-thread workgroups: 256 CUs x 4
+#endif
+__device__ __forceinline__ void tail_prio(bool in_tail, int remaining, int third)
+{
+    if (!SVBRDF_K3_TAIL_PRIO || !in_tail) return;
+    if (remaining > 2 * third) __builtin_amdgcn_s_setprio(2);
+    else if (remaining > third) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 #ifndef SVBRDF_K3_REMAT_TARGET
 #define SVBRDF_K3_REMAT_TARGET 0      // experiment: reload + re-prepare the target maps in every pass
 #endif
@@ -933,11 +991,14 @@ struct RematTarget {                  // where the target's planes of this pixel
     size_t plane, pix;
 };
 
-template <int NL, bool WITH_GRAD>
+template <int NL, bool WITH_GRAD, int G = 1>
 __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt_in, float x, float y,
                                                  const float *__restrict__ scp, const float *sc_lds, int S,
                                                  float eps, float inv_count, Grad &acc, RematTarget rt = RematTarget{nullptr, 0, 0})
 {
+    // G > 1 (scene-split workgroups, k_rendering_loss_split): this wave shades every G-th render of the item, `scp`
+    // points at its first row and `S` is the number of renders it owns; consecutive rows of the wave are ST floats apart
+    constexpr int ST = 9 * G;
     float lsum = 0.0f;
     const VConst K = make_vconst();
     eps = vreg(eps);
@@ -947,19 +1008,27 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt_
     const long long tm0 = clock64(), wc0 = wall_clock64();
 #endif
     if (WITH_GRAD) {
+        [[maybe_unused]] bool in_tail = SVBRDF_K3_TAIL_PRIO == 2;
+        [[maybe_unused]] const int third = (S + 2) / 3;
+        if (SVBRDF_K3_TAIL_PRIO == 1) {
+            const unsigned nblocks = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+            in_tail = bid + SVBRDF_K3_CAPACITY >= nblocks;
+            if (!in_tail) __builtin_amdgcn_s_setprio(3);
+        }
         load_scene(scp, sc);
         Geom ga = geometry(K, sc, x, y), gb;                     // render 0
-        load_scene(scp + (S > 1 ? 9 : 0), sc);                   // scalars of render 1
+        load_scene(scp + (S > 1 ? ST : 0), sc);                  // scalars of render 1
         // One pass = shade render s with geometry G_CUR while the geometry of render s+1 goes into G_NEXT.  The loop
         // body holds TWO passes with the roles of ga / gb swapped, so the pipelined geometry never has to be copied
         // from a "next" to a "current" register set (9 v_mov per render in the rolled loop).
-#define SVBRDF_K3_PASS(G_CUR, G_NEXT)                                                                              \
+#define SVBRDF_K3_PASS(G_CUR, G_NEXT, SI)                                                                             \
         {                                                                                                          \
+            tail_prio(in_tail, S - (SI), third);                                                                   \
             asm volatile("" ::"s"(sc[0]), "s"(sc[8]));           /* the wait for sc lands here, before the next loads */ \
             float cur[9];                                                                                          \
             _Pragma("unroll") for (int i = 0; i < 9; ++i) cur[i] = sc[i];                                          \
-            load_scene(scp + (s + 2 < S ? 18 : (s + 1 < S ? 9 : 0)), sc);                                           \
-            scp += (s + 1 < S) ? 9 : 0;                                                                            \
+            load_scene(scp + ((SI) + 2 < S ? 2 * ST : ((SI) + 1 < S ? ST : 0)), sc);                               \
+            scp += ((SI) + 1 < S) ? ST : 0;                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
             /* two independent streams from here to the end of the pass: */                                        \
             G_NEXT = geometry(K, cur, x, y);                     /* render s+1 (a harmless repeat on the last pass) */ \
@@ -974,16 +1043,31 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt_
                 loss_pixel_scene_any<NL, WITH_GRAD>(K, G_CUR, mi, mt_in, eps, inv_count, lsum, acc);               \
             }                                                                                                      \
         }
-        if (SVBRDF_K3_UNROLL2) {
+        if (SVBRDF_K3_UNROLL2 && SVBRDF_K3_PEEL_LAST) {
+            // the last render of the wave has no successor whose geometry could ride along: it is shaded by a copy of
+            // the pass without the pipelined half (one copy per parity of S) instead of recomputing a geometry nobody
+            // uses (~60 VALU + 3 transcendentals per pixel)
+            int s = 0;
+            for (; s + 2 < S; s += 2) {                          // whole trips: two pipelined passes each
+                SVBRDF_K3_PASS(ga, gb, s)
+                SVBRDF_K3_PASS(gb, ga, s + 1)
+            }
+            if (s + 1 < S) {                                     // S - s == 2
+                SVBRDF_K3_PASS(ga, gb, s)
+                loss_pixel_scene_any<NL, WITH_GRAD>(K, gb, mi, mt_in, eps, inv_count, lsum, acc);
+            } else {                                             // S - s == 1
+                loss_pixel_scene_any<NL, WITH_GRAD>(K, ga, mi, mt_in, eps, inv_count, lsum, acc);
+            }
+        } else if (SVBRDF_K3_UNROLL2) {
             for (int s = 0;;) {
-                SVBRDF_K3_PASS(ga, gb)
+                SVBRDF_K3_PASS(ga, gb, s)
                 if (++s >= S) break;
-                SVBRDF_K3_PASS(gb, ga)
+                SVBRDF_K3_PASS(gb, ga, s)
                 if (++s >= S) break;
             }
         } else {
             for (int s = 0; s < S; ++s) {
-                SVBRDF_K3_PASS(ga, gb)
+                SVBRDF_K3_PASS(ga, gb, s)
                 ga = gb;
             }
         }
@@ -1075,9 +1159,92 @@ __device__ __forceinline__ void fake_maps(size_t pix, float shift, Maps &m)
     for (int k = 0; k < 3; ++k) { m.d[k] = 0.2f + 0.5f * t; m.r[k] = 0.3f + t; m.s[k] = 0.1f + 0.25f * t * (float)(k + 1); }
 }
 
-// One thread = one pixel (VEC = 1: the kernel is VALU-bound, wider loads measured no gain
-// and cost occupancy).  WITH_L1 adds SVBRDFL1Loss on the 24 values already in registers.
-template <bool WITH_GRAD, bool WITH_L1, bool HEAD>
+// Loss reduction, workgroup level: one lane adds its workgroup's partial sum `t` (fixed point) to the workgroup's slot
+// with ONE returning atomic that also counts the slot's arrivals; returns true for the workgroup that completed the
+// last slot of the launch (the finisher).
+__device__ __forceinline__ bool loss_arrive(float t, float fixed_scale, unsigned long long *__restrict__ ws)
+{
+    const unsigned nblocks = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned slot = bid & (kLossSlots - 1);
+    const unsigned slot_blocks = (nblocks - slot + kLossSlots - 1) / kLossSlots;
+    // The scale keeps every legitimate partial sum below 2^47 (loss_impl).  A partial sum that is NaN, infinite
+    // or beyond that (NaN/inf maps, or radiances no renderer input can produce) must neither be cast (undefined
+    // for NaN/inf) nor reach the arrival count in the word's top bits: it contributes 0 and raises the sticky
+    // non-finite flag next to the ticket counter instead, and the finisher reports NaN -- as the reference's
+    // log/L1 chain would (isfinite(loss) guards keep working) -- and leaves the scratch zeroed as always.
+    // The bound is per workgroup: the slot_blocks partial sums of one slot must not carry into the arrival count
+    // together either, so each stays below 2^47 / slot_blocks -- still above every legitimate value (the host picks
+    // the scale so that slot_blocks maximal partial sums fit 2^47), but finite absurd maps (|dlog| of 70-110 per
+    // term) can no longer add up past bit 48, keep the finisher from firing and leave the scratch dirty.
+    const float scaled = fma_(t, fixed_scale, 0.5f);
+    const float limit = 140737488355328.0f * 0.999f * rcp_((float)slot_blocks);     // 2^47 / slot_blocks
+    const bool finite = scaled >= 0.0f && scaled < limit;                            // false for NaN
+    const unsigned long long fixed = finite ? (unsigned long long)scaled : 0ULL;
+    if (!finite) {
+        atomicOr(&ws[kLossSlots], kLossNonFiniteFlag);
+        __threadfence();        // the flag is visible device-wide before this workgroup's arrival is
+    }
+    // device-scope returning atomic, performed at the memory side: add + arrival count in one
+    const unsigned long long old = atomicAdd(&ws[slot], (1ULL << kLossCountShift) | fixed);
+    if ((unsigned)(old >> kLossCountShift) + 1 == slot_blocks) {
+        const unsigned nslots = nblocks < (unsigned)kLossSlots ? nblocks : (unsigned)kLossSlots;
+        const unsigned long long ticket = atomicAdd(&ws[kLossSlots], 1ULL);
+        if ((unsigned)(ticket & kLossTicketMask) + 1 == nslots) return true;
+    }
+    return false;
+}
+
+// the finisher's first wave (`lane` = 0..63): every slot is complete (its completer drew its ticket after its add had
+// returned): fetch-and-clear all slots in parallel, integer wave reduction, write the mean
+__device__ __forceinline__ void loss_finish(unsigned lane, unsigned long long *__restrict__ ws, float *__restrict__ loss_out,
+                                            double loss_scale)
+{
+    const unsigned nblocks = gridDim.x * gridDim.y;
+    unsigned long long v = 0;
+    if (lane < (unsigned)kLossSlots && lane < nblocks) v = atomicExch(&ws[lane], 0ULL) & kLossSumMask;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) {
+        __threadfence();
+        const unsigned long long tail = atomicExch(&ws[kLossSlots], 0ULL);
+        loss_out[0] = (tail & kLossNonFiniteFlag) ? __builtin_nanf("") : (float)((double)v * loss_scale);
+    }
+}
+
+// the gradient planes of one pixel: 12 channels, or the 9 of the encoded head output (chain rule through decode_head)
+template <bool HEAD>
+__device__ __forceinline__ void store_pixel_grad(const Head &head, const Grad &acc, float *__restrict__ grad_input, int b,
+                                                 size_t plane, size_t pix, [[maybe_unused]] float lsum)
+{
+    if (HEAD) {
+        float ge[9];
+        head_bwd(head, acc, ge);
+        float *__restrict__ gp = grad_input + (size_t)b * 9 * plane;
+        if (SVBRDF_K3_ADDR32) {
+            const PlaneBuf pb = plane_buf(gp, 9, plane, pix);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) plane_store(pb, k, ge[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) gp[(size_t)k * plane + pix] = ge[k];
+        }
+    } else {
+        if (SVBRDF_ABLATE != 7 || lsum == -12345.0f)
+            store_grads_k3(grad_input + (size_t)b * 12 * plane, plane, pix, acc);
+    }
+}
+
+// G == 1: one thread = one pixel, all S renders of it (VEC = 1: the kernel is VALU-bound, wider loads measured no gain
+// and cost occupancy); workgroup = 256 pixels.
+// G > 1 (forward+adjoint kernels only, k_rendering_loss_split): workgroup = 64 pixels x G waves.  Wave g shades renders
+// g, g+G, g+2G, ... of every pixel of the block; waves 1..G-1 hand their 12 gradient partials and their loss partial to
+// wave 0 through LDS, which adds them IN WAVE ORDER (bitwise reproducible), stores the gradient and takes part in the loss
+// reduction.  Same bytes from HBM (the G waves read the same 24 plane lines: one miss, G-1 hits in the CU's cache or L2),
+// G times the per-pixel prologue, but G times as many, G times shorter waves: a launch of config 2 is 6 resident rounds of
+// short waves instead of 2 rounds of long ones, whose first round starts behind ONE burst of all its loads and whose last
+// waves run alone on their SIMDs at half the issue rate.
+// WITH_L1 adds SVBRDFL1Loss on the 24 values already in registers (wave 0 only when G > 1).
+template <bool WITH_GRAD, bool WITH_L1, bool HEAD, int G = 1, bool EARLY_COORDS = false>
 __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ input, const float *__restrict__ target,
                                                     const float *__restrict__ scenes, const float *__restrict__ xrow,
                                                     float eps, float inv_count, double loss_scale, float fixed_scale,
@@ -1085,21 +1252,55 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
                                                     unsigned long long *__restrict__ ws, float *__restrict__ loss_out,
                                                     int S, int H, int W)
 {
-    __shared__ float wave_part[kLossThreads / 64];
+    static_assert(G == 1 || WITH_GRAD, "scene-split workgroups exist for the forward+adjoint kernels only");
     extern __shared__ __attribute__((aligned(16))) float sc_lds[];      // [S][9] scene scalars of batch item b
     constexpr float kLn2 = 0.693147180559945309417f;
     const size_t plane = (size_t)H * W;
-    const size_t pix = (size_t)blockIdx.x * kLossThreads + threadIdx.x;
+    const int grp = G == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave-uniform
+    const unsigned lane = G == 1 ? threadIdx.x : (threadIdx.x & 63u);
+    const size_t pix = (size_t)blockIdx.x * (G == 1 ? kLossThreads : 64) + lane;
     const int b = blockIdx.y;
     const bool active = pix < plane;
     float lsum = 0.0f;
+    Grad acc;
+    Head head;
+#if SVBRDF_TIMING
+    const long long t_entry = wall_clock64();
+#endif
+#if SVBRDF_K3_STAGGER
+    {   // experiment: the first resident round issues its plane loads in four layers (workgroup >> 8 = which of a CU's
+        // four workgroup slots, if placement is round-robin), SVBRDF_K3_STAGGER x 64 cycles apart
+        const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned layer = bid >> 8;
+        if (layer == 1) __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER);
+        else if (layer == 2) __builtin_amdgcn_s_sleep(2 * SVBRDF_K3_STAGGER);
+        else if (layer == 3) __builtin_amdgcn_s_sleep(3 * SVBRDF_K3_STAGGER);
+    }
+#endif
     if (!WITH_GRAD) {    // forward-only kernels stage the scene table of batch item b in LDS (see loss_scene_loop)
         for (int i = threadIdx.x; i < S * 9; i += kLossThreads) sc_lds[i] = scenes[(size_t)b * S * 9 + i];
         __syncthreads();
     }
     if (active) {
         Maps in[1], tg[1];
-        Head head;
+        // The pixel's two coordinates come from the xrow table.  Left to the compiler they are loaded AFTER the wait for
+        // the 24 plane loads (and the scene scalars after them): three memory round trips in series in front of every
+        // wave's first geometry, and in the first resident round of a launch each of them queues behind the burst of
+        // all the waves' plane loads.  Issued here, in front of the plane loads, they are in flight together with them.
+        // Inline asm because the scheduler otherwise sinks them back to their use; the compiler does not count these two
+        // loads in its s_waitcnt bookkeeping, which is safe only because they are OLDER than every load it tracks (the
+        // counter retires in order, extra older loads make its waits stricter) -- tests/test_isa_guard.py checks that
+        // no plane load is issued before them -- and they are consumed behind an explicit vmcnt(0).
+        [[maybe_unused]] float x_early = 0.0f, y_early = 0.0f;
+        // (by-value-table kernels only: the device-table variants sit at the register limit and answer two more live
+        // values in the prologue with spills between the plane loads)
+        const bool early_coords = SVBRDF_K3_EARLY_COORDS && EARLY_COORDS && WITH_GRAD && (W & (W - 1)) == 0;
+        if (early_coords) {
+            const unsigned p32 = (unsigned)pix, sh = (unsigned)__builtin_ctz((unsigned)W);
+            const float *px = xrow + (p32 & (unsigned)(W - 1)), *py = xrow + (p32 >> sh);
+            asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
+                         : "=&v"(x_early), "=&v"(y_early) : "v"(px), "v"(py) : "memory");
+        }
         if (HEAD) {     // input is the [B,9,H,W] post-tanh generator output
             float e[9];
             const float *__restrict__ ip = input + (size_t)b * 9 * plane;
@@ -1111,17 +1312,19 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
 #pragma unroll
                 for (int k = 0; k < 9; ++k) e[k] = ip[(size_t)k * plane + pix];
             }
+            if (G > 1 && WITH_L1) pin_loaded(e, 9);
             head = decode_head(e, in[0]);
         } else {
             if (SVBRDF_ABLATE == 6) fake_maps(pix, 0.0f, in[0]);
             else load_maps_k3(input + (size_t)b * 12 * plane, plane, pix, in[0]);
+            if (G > 1 && WITH_L1) pin_maps(in[0]);
         }
         if (SVBRDF_ABLATE == 6) fake_maps(pix, 0.05f, tg[0]);
         else load_maps_k3(target + (size_t)b * 12 * plane, plane, pix, tg[0]);
-        Grad acc;
+        if (G > 1 && WITH_L1) pin_maps(tg[0]);
         zero_grad(acc);
         float l1sum = 0.0f;
-        if (WITH_L1) {
+        if (WITH_L1 && (G == 1 || grp == 0)) {
             // losses.py:7-19.  Same economy of transcendentals as in loss_pixel_scene: the six 1/(x + eps)
             // of the log terms' derivatives come from ONE v_rcp of their product (all six lie in
             // [eps_l1, 1 + eps_l1]: no scaling needed), and log(a) - log(b) is one log of the quotient formed
@@ -1168,7 +1371,11 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         const bool tied = tied_roughness(in[0]) && tied_roughness(tg[0]);
         const MapK mi = prepare<WITH_GRAD>(in[0]), mt = prepare<false>(tg[0]);
         float x[1], y;
-        if ((W & (W - 1)) == 0) {
+        if (early_coords) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(x_early), "+v"(y_early) : : "memory");
+            x[0] = x_early;
+            y = -y_early;
+        } else if ((W & (W - 1)) == 0) {
             // power-of-two width (256, 512: every BASELINE configuration): row and column by shift and mask instead of a
             // 64-bit division (~25 VALU instructions, several of them quarter-rate integer multiplies)
             const unsigned p32 = (unsigned)pix, sh = (unsigned)__builtin_ctz((unsigned)W);
@@ -1189,83 +1396,74 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
                               (((tg[0].n[0] + tg[0].n[1]) + (tg[0].n[2] + tg[0].r[0])) + (tg[0].r[1] + tg[0].r[2]));
             x[0] += chk - chk;
         }
-        const float *__restrict__ scp = scenes + (size_t)b * S * 9;
-        if (__all(tied))     // wave-uniform: every lane's input AND target roughness channels are tied
-            lsum = loss_scene_loop<1, WITH_GRAD>(mi, mt, x[0], y, scp, sc_lds, S, eps, inv_count, acc,
-                                                 RematTarget{target + (size_t)b * 12 * plane, plane, pix});
-        else
-            lsum = loss_scene_loop<3, WITH_GRAD>(mi, mt, x[0], y, scp, sc_lds, S, eps, inv_count, acc);
+        // renders of this wave: all S of the item (G == 1), or rows grp, grp + G, ... of it
+        const int S_own = G == 1 ? S : (S - grp + G - 1) / G;
+        const float *__restrict__ scp = scenes + ((size_t)b * S + grp) * 9;
+        if (G == 1 || S_own > 0) {
+            if (__all(tied))     // wave-uniform: every lane's input AND target roughness channels are tied
+                lsum = loss_scene_loop<1, WITH_GRAD, G>(mi, mt, x[0], y, scp, sc_lds, S_own, eps, inv_count, acc,
+                                                        RematTarget{target + (size_t)b * 12 * plane, plane, pix});
+            else
+                lsum = loss_scene_loop<3, WITH_GRAD, G>(mi, mt, x[0], y, scp, sc_lds, S_own, eps, inv_count, acc);
+        }
         if (WITH_L1) lsum = fma_(l1sum, l1.sum_scale, lsum);
-        if (WITH_GRAD) {
-            if (HEAD) {
-                float ge[9];
-                head_bwd(head, acc, ge);
-                float *__restrict__ gp = grad_input + (size_t)b * 9 * plane;
-                if (SVBRDF_K3_ADDR32) {
-                    const PlaneBuf pb = plane_buf(gp, 9, plane, pix);
+#if SVBRDF_TIMING
+        if (WITH_GRAD && !HEAD) {       // timing build: entry / exit stamps of the wave beside the loop's (loss_scene_loop)
+            acc.d[0] = (float)(t_entry & 0xffffff);
+            acc.d[1] = (float)(wall_clock64() & 0xffffff);
+            if (G > 1) {                // every wave of a scene-split workgroup reports its own loop stamps: planes 3 grp ..
+                const PlaneBuf pb = plane_buf(grad_input + (size_t)b * 12 * plane, 12, plane, pix);
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) plane_store(pb, k, ge[k]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) gp[(size_t)k * plane + pix] = ge[k];
-                }
-            } else {
-                if (SVBRDF_ABLATE != 7 || lsum == -12345.0f)
-                    store_grads_k3(grad_input + (size_t)b * 12 * plane, plane, pix, acc);
+                for (int k = 0; k < 3; ++k) plane_store(pb, 3 * grp + k, acc.n[k]);
             }
         }
+#endif
+        if (WITH_GRAD && G == 1) store_pixel_grad<HEAD>(head, acc, grad_input, b, plane, pix, lsum);
     }
-    lsum = wave_sum(lsum);
-    if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = lsum;
-    __shared__ int finisher;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        finisher = 0;
-        float t = 0.0f;
+    if constexpr (G > 1) {
+        // combine the G partial results of every pixel in wave 0, in wave order
+        __shared__ float part[(G - 1) * 13 * 64];
+        if (grp != 0) {
+            float *__restrict__ q = part + (grp - 1) * 13 * 64 + lane;
 #pragma unroll
-        for (int w = 0; w < kLossThreads / 64; ++w) t += wave_part[w];
-        const unsigned nblocks = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
-        const unsigned slot = bid & (kLossSlots - 1);
-        const unsigned slot_blocks = (nblocks - slot + kLossSlots - 1) / kLossSlots;
-        // The scale keeps every legitimate partial sum below 2^47 (loss_impl).  A partial sum that is NaN, infinite
-        // or beyond that (NaN/inf maps, or radiances no renderer input can produce) must neither be cast (undefined
-        // for NaN/inf) nor reach the arrival count in the word's top bits: it contributes 0 and raises the sticky
-        // non-finite flag next to the ticket counter instead, and the finisher reports NaN -- as the reference's
-        // log/L1 chain would (isfinite(loss) guards keep working) -- and leaves the scratch zeroed as always.
-        // The bound is per workgroup: the slot_blocks partial sums of one slot must not carry into the arrival count
-        // together either, so each stays below 2^47 / slot_blocks -- still above every legitimate value (the host picks
-        // the scale so that slot_blocks maximal partial sums fit 2^47), but finite absurd maps (|dlog| of 70-110 per
-        // term) can no longer add up past bit 48, keep the finisher from firing and leave the scratch dirty.
-        const float scaled = fma_(t, fixed_scale, 0.5f);
-        const float limit = 140737488355328.0f * 0.999f * rcp_((float)slot_blocks);     // 2^47 / slot_blocks
-        const bool finite = scaled >= 0.0f && scaled < limit;                            // false for NaN
-        const unsigned long long fixed = finite ? (unsigned long long)scaled : 0ULL;
-        if (!finite) {
-            atomicOr(&ws[kLossSlots], kLossNonFiniteFlag);
-            __threadfence();        // the flag is visible device-wide before this workgroup's arrival is
+            for (int k = 0; k < 3; ++k) {
+                q[(0 + k) * 64] = acc.n[k]; q[(3 + k) * 64] = acc.d[k];
+                q[(6 + k) * 64] = acc.r[k]; q[(9 + k) * 64] = acc.s[k];
+            }
+            q[12 * 64] = lsum;
         }
-        // device-scope returning atomic, performed at the memory side: add + arrival count in one
-        const unsigned long long old = atomicAdd(&ws[slot], (1ULL << kLossCountShift) | fixed);
-        if ((unsigned)(old >> kLossCountShift) + 1 == slot_blocks) {
-            const unsigned nslots = nblocks < (unsigned)kLossSlots ? nblocks : (unsigned)kLossSlots;
-            const unsigned long long ticket = atomicAdd(&ws[kLossSlots], 1ULL);
-            if ((unsigned)(ticket & kLossTicketMask) + 1 == nslots) finisher = 1;
-        }
-    }
-    __syncthreads();
-    if (finisher && threadIdx.x < 64) {
-        // every slot is complete (its completer drew its ticket after its add had returned):
-        // one wave fetches-and-clears all slots in parallel, integer wave reduction
-        const unsigned nblocks = gridDim.x * gridDim.y;
-        unsigned long long v = 0;
-        if (threadIdx.x < (unsigned)kLossSlots && threadIdx.x < nblocks) v = atomicExch(&ws[threadIdx.x], 0ULL) & kLossSumMask;
+        __syncthreads();
+        if (grp != 0) return;           // waves 1..G-1 are done; no barrier follows
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        for (int w = 1; w < G; ++w) {
+            const float *__restrict__ q = part + (w - 1) * 13 * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                acc.n[k] += q[(0 + k) * 64]; acc.d[k] += q[(3 + k) * 64];
+                acc.r[k] += q[(6 + k) * 64]; acc.s[k] += q[(9 + k) * 64];
+            }
+            lsum += q[12 * 64];
+        }
+        if (active && !SVBRDF_TIMING) store_pixel_grad<HEAD>(head, acc, grad_input, b, plane, pix, lsum);
+        if (!active) lsum = 0.0f;
+        lsum = wave_sum(lsum);
+        bool fin = false;
+        if (lane == 0) fin = loss_arrive(lsum, fixed_scale, ws);
+        if (__any(fin)) loss_finish(lane, ws, loss_out, loss_scale);
+    } else {
+        __shared__ float wave_part[kLossThreads / 64];
+        __shared__ int finisher;
+        lsum = wave_sum(lsum);
+        if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = lsum;
+        __syncthreads();
         if (threadIdx.x == 0) {
-            __threadfence();
-            const unsigned long long tail = atomicExch(&ws[kLossSlots], 0ULL);
-            loss_out[0] = (tail & kLossNonFiniteFlag) ? __builtin_nanf("") : (float)((double)v * loss_scale);
+            float t = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kLossThreads / 64; ++w) t += wave_part[w];
+            finisher = loss_arrive(t, fixed_scale, ws) ? 1 : 0;
         }
+        __syncthreads();
+        if (finisher && threadIdx.x < 64) loss_finish(threadIdx.x, ws, loss_out, loss_scale);
     }
 }
 
@@ -1307,9 +1505,46 @@ __global__ SVBRDF_K3_ATTRS void k_rendering_loss_inl([[maybe_unused]] const Scen
                                                      float *__restrict__ loss_out, int S, int H, int W)
 {
     const float *__restrict__ rows = (const float *)__builtin_amdgcn_kernarg_segment_ptr();
-    rendering_loss_body<WITH_GRAD, WITH_L1, HEAD>(input, target, rows, xrow, eps, inv_count, loss_scale, fixed_scale,
-                                                  l1, grad_input, ws, loss_out, S, H, W);
+    rendering_loss_body<WITH_GRAD, WITH_L1, HEAD, 1, true>(input, target, rows, xrow, eps, inv_count, loss_scale,
+                                                           fixed_scale, l1, grad_input, ws, loss_out, S, H, W);
 }
+
+// Scene-split workgroups (rendering_loss_body with G > 1): 64 pixels x G waves, forward+adjoint only.  An experiment of
+// round 4 that LOST (profiles/r04_ab_split.txt, DESIGN.md section 4.4: the per-wave fixed work -- plane loads, prepare(),
+// the un-pipelined first geometry, the finalise -- is worth 0.75 renders, so three waves per pixel cost 15 % more issue
+// slots than they recover from the tail): compiled only with -DSVBRDF_K3_SPLIT_VARIANTS=1 (tools/build_variant.sh), where
+// SVBRDF_K3_SPLIT=2|3|4 in the environment selects the layout.
+#if SVBRDF_K3_SPLIT_VARIANTS
+#define SVBRDF_K3_SPLIT_ATTRS(G) __launch_bounds__(64 * (G)) __attribute__((amdgpu_waves_per_eu(SVBRDF_K3_MIN_WAVES, 8)))
+template <bool WITH_L1, bool HEAD, int G>
+__global__ SVBRDF_K3_SPLIT_ATTRS(G) void k_rendering_loss_split(const float *__restrict__ input,
+                                                                const float *__restrict__ target,
+                                                                const float *__restrict__ scenes,
+                                                                const float *__restrict__ xrow, float eps, float inv_count,
+                                                                double loss_scale, float fixed_scale, L1Params l1,
+                                                                float *__restrict__ grad_input,
+                                                                unsigned long long *__restrict__ ws,
+                                                                float *__restrict__ loss_out, int S, int H, int W)
+{
+    rendering_loss_body<true, WITH_L1, HEAD, G>(input, target, scenes, xrow, eps, inv_count, loss_scale, fixed_scale, l1,
+                                                grad_input, ws, loss_out, S, H, W);
+}
+
+template <bool WITH_L1, bool HEAD, int G>
+__global__ SVBRDF_K3_SPLIT_ATTRS(G) void k_rendering_loss_split_inl([[maybe_unused]] const SceneBlock table,
+                                                                    const float *__restrict__ input,
+                                                                    const float *__restrict__ target,
+                                                                    const float *__restrict__ xrow, float eps,
+                                                                    float inv_count, double loss_scale, float fixed_scale,
+                                                                    L1Params l1, float *__restrict__ grad_input,
+                                                                    unsigned long long *__restrict__ ws,
+                                                                    float *__restrict__ loss_out, int S, int H, int W)
+{
+    const float *__restrict__ rows = (const float *)__builtin_amdgcn_kernarg_segment_ptr();
+    rendering_loss_body<true, WITH_L1, HEAD, G>(input, target, rows, xrow, eps, inv_count, loss_scale, fixed_scale, l1,
+                                                grad_input, ws, loss_out, S, H, W);
+}
+#endif  // SVBRDF_K3_SPLIT_VARIANTS
 
 #if defined(SVBRDF_ISA_PROBE)
 // tests/test_isa_guard.py: dot3 alone, to check in the assembly that its products are not contracted into FMAs
@@ -1496,25 +1731,39 @@ dim3 grid_for(int B, int H, int W, int vec)
 
 // launches one K3 variant; `rows` = the host scene table for the by-value kernels (NULL: device table `scenes`).
 // WHICH selects the variants this translation unit instantiates: 0 = <G, L1=0, HEAD=0> only, 1 = the other three,
-// 2 = all four.
+// 2 = all four.  `split` > 1 (forward+adjoint only): the scene-split kernels with that many waves per 64-pixel block;
+// the caller sized `grid` for the layout it asks for.
 template <bool G, int WHICH>
-void launch_k3(bool with_l1, bool head, const float *rows, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st,
+void launch_k3(int split, bool with_l1, bool head, const float *rows, dim3 grid, size_t lds_bytes, hipStream_t st,
                const float *input, const float *target, const float *scenes, const float *xrow, float eps,
                float inv_count, double loss_scale, float fixed_scale, L1Params l1, float *grad_input,
                unsigned long long *ws, float *loss_out, int B, int S, int H, int W)
 {
     SceneBlock block_arg;      // only the first B*S rows are ever read
     if (rows) std::memcpy(block_arg.v, rows, (size_t)B * S * 9 * sizeof(float));
-#define SVBRDF_LAUNCH_K3(L, HD)                                                                                 \
+#define SVBRDF_LAUNCH_K3_AS(KERNEL, KERNEL_INL, THREADS)                                                        \
     do {                                                                                                        \
         if (rows)                                                                                               \
-            hipLaunchKernelGGL((k_rendering_loss_inl<G, L, HD>), grid, block, lds_bytes, st, block_arg, input,   \
-                               target, xrow, eps, inv_count, loss_scale, fixed_scale, l1, grad_input, ws,       \
-                               loss_out, S, H, W);                                                              \
+            hipLaunchKernelGGL(KERNEL_INL, grid, dim3(THREADS), lds_bytes, st, block_arg, input, target, xrow,  \
+                               eps, inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, S, H, W); \
         else                                                                                                    \
-            hipLaunchKernelGGL((k_rendering_loss<G, L, HD>), grid, block, lds_bytes, st, input, target, scenes, \
-                               xrow, eps, inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, S,  \
-                               H, W);                                                                           \
+            hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), lds_bytes, st, input, target, scenes, xrow, eps,    \
+                               inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, S, H, W);      \
+    } while (0)
+#if SVBRDF_K3_SPLIT_VARIANTS
+#define SVBRDF_LAUNCH_K3_SPLIT(L, HD)                                                                           \
+    if constexpr (G) {                                                                                          \
+        if (split == 2) { SVBRDF_LAUNCH_K3_AS((k_rendering_loss_split<L, HD, 2>), (k_rendering_loss_split_inl<L, HD, 2>), 128); break; } \
+        if (split == 3) { SVBRDF_LAUNCH_K3_AS((k_rendering_loss_split<L, HD, 3>), (k_rendering_loss_split_inl<L, HD, 3>), 192); break; } \
+        if (split == 4) { SVBRDF_LAUNCH_K3_AS((k_rendering_loss_split<L, HD, 4>), (k_rendering_loss_split_inl<L, HD, 4>), 256); break; } \
+    }
+#else
+#define SVBRDF_LAUNCH_K3_SPLIT(L, HD) (void)split;
+#endif
+#define SVBRDF_LAUNCH_K3(L, HD)                                                                                 \
+    do {                                                                                                        \
+        SVBRDF_LAUNCH_K3_SPLIT(L, HD)                                                                           \
+        SVBRDF_LAUNCH_K3_AS((k_rendering_loss<G, L, HD>), (k_rendering_loss_inl<G, L, HD>), kLossThreads);      \
     } while (0)
     if constexpr (WHICH != 0) {
         if (head) { if (with_l1) SVBRDF_LAUNCH_K3(true, true); else SVBRDF_LAUNCH_K3(false, true); }
@@ -1524,13 +1773,15 @@ void launch_k3(bool with_l1, bool head, const float *rows, dim3 grid, dim3 block
         if (!head && !with_l1) SVBRDF_LAUNCH_K3(false, false);
     }
 #undef SVBRDF_LAUNCH_K3
+#undef SVBRDF_LAUNCH_K3_SPLIT
+#undef SVBRDF_LAUNCH_K3_AS
 }
 
 }  // namespace
 
 // the forward+adjoint variants live in their own translation units (see the top of this file)
 #define SVBRDF_K3_ADJOINT_ARGS                                                                                        \
-    int with_l1, int head, const float *rows, unsigned gx, unsigned gy, size_t lds_bytes, void *stream,                 \
+    int split, int with_l1, int head, const float *rows, unsigned gx, unsigned gy, size_t lds_bytes, void *stream,      \
         const float *input, const float *target, const float *scenes, const float *xrow, float eps, float inv_count,   \
         double loss_scale, float fixed_scale, float l1_sum_scale, float l1_grad_scale, float l1_eps, float *grad_input, \
         unsigned long long *ws, float *loss_out, int B, int S, int H, int W
@@ -1539,7 +1790,7 @@ extern "C" __attribute__((visibility("hidden"))) void svbrdf_internal_launch_k3_
 #if SVBRDF_TU_ADJOINT_PLAIN
 void svbrdf_internal_launch_k3_adjoint_plain(SVBRDF_K3_ADJOINT_ARGS)
 {
-    launch_k3<true, 0>(with_l1 != 0, head != 0, rows, dim3(gx, gy, 1), dim3(kLossThreads), lds_bytes,
+    launch_k3<true, 0>(split, with_l1 != 0, head != 0, rows, dim3(gx, gy, 1), lds_bytes,
                        static_cast<hipStream_t>(stream), input, target, scenes, xrow, eps, inv_count, loss_scale, fixed_scale,
                        L1Params{l1_sum_scale, l1_grad_scale, l1_eps}, grad_input, ws, loss_out, B, S, H, W);
 }
@@ -1547,7 +1798,7 @@ void svbrdf_internal_launch_k3_adjoint_plain(SVBRDF_K3_ADJOINT_ARGS)
 #if SVBRDF_TU_ADJOINT_EXTRA
 void svbrdf_internal_launch_k3_adjoint_extra(SVBRDF_K3_ADJOINT_ARGS)
 {
-    launch_k3<true, 1>(with_l1 != 0, head != 0, rows, dim3(gx, gy, 1), dim3(kLossThreads), lds_bytes,
+    launch_k3<true, 1>(split, with_l1 != 0, head != 0, rows, dim3(gx, gy, 1), lds_bytes,
                        static_cast<hipStream_t>(stream), input, target, scenes, xrow, eps, inv_count, loss_scale, fixed_scale,
                        L1Params{l1_sum_scale, l1_grad_scale, l1_eps}, grad_input, ws, loss_out, B, S, H, W);
 }
@@ -1689,6 +1940,26 @@ size_t svbrdf_rendering_loss_workspace_bytes(int B, int S, int H, int W)
     return (kLossSlots + 1) * sizeof(unsigned long long);   // sharded fixed-point accumulators + ticket
 }
 
+// Workgroup layout of a forward+adjoint loss launch: 1 = 256 pixels per workgroup, every thread all renders of its
+// pixel (the product); 2, 3, 4 = 64 pixels x that many waves sharing the renders of a pixel -- only in experiment builds
+// (-DSVBRDF_K3_SPLIT_VARIANTS=1), selected by SVBRDF_K3_SPLIT in the environment (read once).
+static int pick_loss_split([[maybe_unused]] int B, [[maybe_unused]] int S, [[maybe_unused]] long long plane)
+{
+#if SVBRDF_K3_SPLIT_VARIANTS
+    static const int forced = [] {
+        const char *e = std::getenv("SVBRDF_K3_SPLIT");
+        const int v = e ? std::atoi(e) : 1;
+        return (v < 1 || v > 4) ? 1 : v;
+    }();
+    int split = forced > S ? S : forced;       // a wave without renders would only pay the prologue
+    // four times the workgroups must still fit the arrival counters
+    if (split > 1 && (unsigned long long)((plane + 63) / 64) * (unsigned long long)B >= (1ULL << 16) * kLossSlots) split = 1;
+    return split;
+#else
+    return 1;
+#endif
+}
+
 static int loss_impl(const char *who, bool head, bool scenes_on_host, const float *input, const float *target,
                      const float *scenes, const float *xrow, float eps, float l1_weight, float eps_l1,
                      float *loss_out, float *grad_input, void *workspace, size_t workspace_bytes, int B, int S,
@@ -1709,7 +1980,11 @@ static int loss_impl(const char *who, bool head, bool scenes_on_host, const floa
     const long long plane = (long long)H * W;
     if (plane > (1LL << 25))
         return fail(SVBRDF_ERR_DIMS, "loss: H*W exceeds 2^25 (one item's 12 planes are addressed with 32-bit byte offsets)");
-    const dim3 grid((unsigned)((plane + kLossThreads - 1) / kLossThreads), (unsigned)B, 1), block(kLossThreads);
+    // workgroup layout of the forward+adjoint kernels: 256 pixels x all renders (split 1), or 64 pixels x `split` waves
+    // that share the renders of a pixel (rendering_loss_body)
+    const int split = grad_input ? pick_loss_split(B, S, plane) : 1;
+    const long long wg_pixels = split > 1 ? 64 : kLossThreads;
+    const dim3 grid((unsigned)((plane + wg_pixels - 1) / wg_pixels), (unsigned)B, 1);
     const double count = (double)B * S * 3.0 * (double)plane;
     const float inv_count = (float)(1.0 / count);
     unsigned long long *ws = static_cast<unsigned long long *>(workspace);
@@ -1730,10 +2005,10 @@ static int loss_impl(const char *who, bool head, bool scenes_on_host, const floa
     const float *rows = scenes_on_host ? scenes : nullptr;
     if (grad_input)
         (l1_weight != 0.0f || head ? svbrdf_internal_launch_k3_adjoint_extra : svbrdf_internal_launch_k3_adjoint_plain)(
-            l1_weight != 0.0f, head, rows, grid.x, grid.y, lds_bytes, stream, input, target, scenes, xrow, eps, inv_count,
-            loss_scale, fixed_scale, l1.sum_scale, l1.grad_scale, l1.eps, grad_input, ws, loss_out, B, S, H, W);
+            split, l1_weight != 0.0f, head, rows, grid.x, grid.y, lds_bytes, stream, input, target, scenes, xrow, eps,
+            inv_count, loss_scale, fixed_scale, l1.sum_scale, l1.grad_scale, l1.eps, grad_input, ws, loss_out, B, S, H, W);
     else
-        launch_k3<false, 2>(l1_weight != 0.0f, head, rows, grid, block, lds_bytes, st, input, target, scenes, xrow, eps,
+        launch_k3<false, 2>(1, l1_weight != 0.0f, head, rows, grid, lds_bytes, st, input, target, scenes, xrow, eps,
                             inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, B, S, H, W);
     return launch_status(who);
 }

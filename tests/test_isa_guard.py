@@ -102,6 +102,16 @@ def test_plane_loads_are_issued_back_to_back(adjoint_asm, adjoint_extra_asm):
                     start = b
             groups.append((start, loads[-1]))
             assert len(groups) <= 2, "%s: plane loads split into %d groups by s_waitcnt vmcnt" % (k, len(groups))
+            # The two coordinate loads are inline asm the compiler's s_waitcnt bookkeeping does not see; that is safe only
+            # while they are OLDER than every load it tracks (rendering_loss_body): both must precede the first plane
+            # load, and an explicit vmcnt(0) must follow the last one before the prologue's first v_rsq (the geometry).
+            # (the by-value-table kernels, "_inl"; the device-table kernels load their coordinates the ordinary way)
+            coords = [i for i, (_, _, mn, ops) in enumerate(ins[:first_loop]) if mn == "global_load_dword"]
+            early = [i for i in coords if i < loads[0]]
+            assert len(early) == (2 if "_inl" in k else 0), "%s: %d coordinate loads in front of the plane loads" % (k, len(early))
+            if early:
+                rsq = next(i for i, (_, _, mn, _) in enumerate(ins) if mn and mn.startswith("v_rsq_f32") and i > loads[-1])
+                assert any(m == "s_waitcnt" and o.strip() == "vmcnt(0)" for _, _, m, o in ins[loads[-1]:rsq] if m), k
 
 
 def test_scene_loops_instruction_budget(adjoint_asm):

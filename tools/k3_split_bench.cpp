@@ -18,6 +18,7 @@ static decltype(&svbrdf_make_xrow) p_make_xrow;
 static decltype(&svbrdf_rendering_loss_workspace_bytes) p_ws_bytes;
 static decltype(&svbrdf_mixed_loss_fwd_bwd_host_scenes) p_loss, p_head;
 static decltype(&svbrdf_last_error) p_last_error;
+static decltype(&svbrdf_scale_inplace) p_scale;
 #define svbrdf_make_xrow p_make_xrow
 #define svbrdf_rendering_loss_workspace_bytes p_ws_bytes
 #define svbrdf_mixed_loss_fwd_bwd_host_scenes p_loss
@@ -38,6 +39,7 @@ int main()
     p_loss = (decltype(p_loss))dlsym(h, "svbrdf_mixed_loss_fwd_bwd_host_scenes");
     p_last_error = (decltype(p_last_error))dlsym(h, "svbrdf_last_error");
     p_head = (decltype(p_head))dlsym(h, "svbrdf_head_loss_fwd_bwd_host_scenes");
+    p_scale = (decltype(p_scale))dlsym(h, "svbrdf_scale_inplace");
     const bool head = std::getenv("K3_HEAD") != nullptr;       // input = [B,9,H,W] encoded head output
     if (head) p_loss = p_head;
     if (!p_make_xrow || !p_ws_bytes || !p_loss || !p_last_error) { std::printf("missing symbols in %s\n", libpath); return 1; }
@@ -82,6 +84,8 @@ int main()
     CK(hipMalloc(&d_xr, W * 4)); CK(hipMalloc(&d_loss, 4 * NS)); CK(hipMalloc(&d_ws, wsb * NS)); CK(hipMemset(d_ws, 0, wsb * NS));
     CK(hipMemcpy(d_in, in.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_tg, tg.data(), n * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_xr, xr.data(), W * 4, hipMemcpyHostToDevice));
+    float *d_one; const float one = 1.0f;
+    CK(hipMalloc(&d_one, 4)); CK(hipMemcpy(d_one, &one, 4, hipMemcpyHostToDevice));
     hipStream_t st[NS];
     for (int i = 0; i < NS; ++i) CK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
     hipEvent_t fork_ev, join_ev[NS];
@@ -103,6 +107,7 @@ int main()
         {"2 halves on 2 streams, free-running", 2, false, false},
         {"full launches alternating on 2 free streams", 1, false, true},
         {"2 halves on ONE stream", -2, false, false},
+        {"launch floor: a kernel that exits at once, back to back", 0, false, false},
     };
     const int rounds = std::getenv("K3_ROUNDS") ? std::atoi(std::getenv("K3_ROUNDS")) : 3;
     for (int round = 0; round < rounds; ++round)
@@ -113,7 +118,9 @@ int main()
                 CK(hipDeviceSynchronize());
                 const auto t0 = std::chrono::steady_clock::now();
                 for (int i = 0; i < steps; ++i) {
-                    if (m.parts < 0) {
+                    if (m.parts == 0) {         // svbrdf_scale_inplace with scale 1: one scalar load, s_endpgm
+                        CA(p_scale(d_grad, d_one, n, st[0]));
+                    } else if (m.parts < 0) {
                         for (int p = 0; p < -m.parts; ++p) CA(launch(p, -m.parts, 0));
                     } else if (m.alternate) {
                         CA(launch(0, 1, i & 1));
