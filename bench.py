@@ -161,6 +161,9 @@ def cpu_baseline(args, inp, tgt, table):
     one, _, _ = _time_eager(1, inp, tgt, table, budget_s=3.0, max_patches=4)
     every = probe[ncpu] if ncpu in probe else _all_cores_child(args, ncpu)
     res = {"value": rate, "unit": "patches/s", "cores": best, "kind": "port",
+           # BASELINE.md section 3 words the baseline as torch.set_num_threads(os.cpu_count()): that figure, flat, beside
+           # `value` (= the best of a few thread counts; eager 256x256 elementwise ops do not scale to 256 threads)
+           "all_cores_threads": ncpu, "all_cores_patches_per_s": every,
            "all_cores": {"threads": ncpu, "patches_per_s": every,
                          "note": "torch.set_num_threads(os.cpu_count()) as BASELINE.md section 3 states it; eager "
                                  "256x256 elementwise ops do not scale that far, so `value` is the best of a few counts"},
@@ -354,7 +357,7 @@ def secondary_kernels(dev, H):
     return out
 
 
-def plumbing_only(args, rank, world):
+def plumbing_only(args, rank, world, placement):
     """--plumbing-only: everything of the multi-rank protocol except the GPU work (CPU test of the launch path)."""
     import torch.distributed as dist
     if world > 1:
@@ -366,14 +369,18 @@ def plumbing_only(args, rank, world):
     if world > 1:
         dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    seen = 1
+    seen, places = 1, [placement]
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         seen = dist.get_world_size()
+        places = [None] * seen
+        dist.all_gather_object(places, placement)
     if rank == 0:
         print(json.dumps({"metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)", "value": None,
                           "unit": "patches/s", "n_gpus": world, "ranks_seen": seen, "plumbing_only": True,
                           "elapsed_max_over_ranks_s": float(t.item()),
+                          "per_rank": {"cpus": [p["cpus"] for p in places], "numa_node": [p["numa_node"] for p in places],
+                                       "cpu_binding": [p["source"] for p in places]},
                           "launch": "self-spawned" if os.environ.get("SVBRDF_SELF_SPAWNED") else "external launcher"}),
               flush=True)
     if world > 1:
@@ -396,17 +403,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (or let bench.py spawn them: run it "
                          "without a rank environment)" % (args.gpus, world))
+    # first thing in a rank, before any GPU call: pin it to the CPUs next to its GPU (launch.py)
+    placement = launch.bind_rank_to_gpu_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), args.share_device)
     if args.plumbing_only:
-        return plumbing_only(args, rank, world)
+        return plumbing_only(args, rank, world, placement)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # The rank's own CPU work is tiny tensors (the scene sampler).  With torch's default intra-op pool -- one thread per
     # core, 256 on the GPU box -- every host-side tensor op that does go parallel (generating the synthetic maps) leaves
     # the pool's workers spinning for ~100-200 ms afterwards, and the launch path of the main thread ran 3-4x slow for that
     # long (seen as a host-bound first leg after each new batch size; profiles/r03_dbg_mixed*.txt).  A small pool, and
     # time-based settling before every timed leg.  (The CPU baseline sets its own thread counts.)
-    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 1) // max(1, world))))
-    if not args.share_device and torch.cuda.device_count() < world:
-        raise SystemExit("--gpus %d but only %d device(s) visible" % (world, torch.cuda.device_count()))
+    torch.set_num_threads(max(1, min(8, placement["n_cpus"])))
+    if not args.share_device and torch.cuda.device_count() <= local_rank:
+        raise SystemExit("local rank %d but only %d device(s) visible" % (local_rank, torch.cuda.device_count()))
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -448,10 +457,10 @@ def main():
     # HIP events around individual kernel launches on the launch stream, on every 32nd timed step (a timing event is an
     # end-of-pipe timestamp: each bracketed launch costs its stream ~10 us of idle once the loop is GPU-bound, so the
     # launches are sampled: 63 samples at the default 2000 steps).  A short timed region (the driver's --steps 20 is 0.8 ms)
-    # gets NO per-launch events -- two bubbles would be 2.5 % of it -- and the samples are taken in an untimed leg right
-    # after it instead.  The roofline is priced with the ONE event pair around the whole region either way.
+    # gets NO per-launch events -- two bubbles would be 2.5 % of it -- and the samples (32 of them) are taken in an untimed
+    # 512-step leg right after it instead.  The roofline is priced with the ONE event pair around the whole region either way.
     sample_in_region = args.steps >= 256
-    n_sample_leg = args.steps if sample_in_region else 128
+    n_sample_leg = args.steps if sample_in_region else 512        # short form: 32 samples (was 8 until round 4)
     stride = 32 if sample_in_region else 16
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           if i % stride == 0 else None for i in range(n_sample_leg)]
@@ -539,10 +548,19 @@ def main():
         mean_loss = distributed.global_mean(last.detach() if nccl else last.detach().cpu()).item()
         every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(every, mine)            # for the record: each rank's own clock, last loss and scene seed
-        per_rank = {"elapsed_s": [float(e[0]) for e in every], "last_loss": [float(e[1]) for e in every],
-                    "scene_seed": [int(e[2]) for e in every]}
+        places = [None] * dist.get_world_size()
+        dist.all_gather_object(places, placement)
+        per_rank = {"elapsed_s": [float(e[0]) for e in every],
+                    "ms_per_step": [1e3 * float(e[0]) / args.steps for e in every],
+                    "patches_per_s": [B * args.steps / float(e[0]) for e in every],
+                    "last_loss": [float(e[1]) for e in every], "scene_seed": [int(e[2]) for e in every],
+                    "cpus": [p["cpus"] for p in places], "numa_node": [p["numa_node"] for p in places],
+                    "cpu_binding": [p["source"] for p in places]}
     else:
         mean_loss = last.item()
+        per_rank = {"elapsed_s": [elapsed], "ms_per_step": [1e3 * elapsed / args.steps],
+                    "patches_per_s": [B * args.steps / elapsed], "cpus": [placement["cpus"]],
+                    "numa_node": [placement["numa_node"]], "cpu_binding": [placement["source"]]}
 
     if not sample_in_region:                # untimed: the per-launch event samples a short timed region does not carry
         _native.set_launch_hook(hook)
@@ -686,6 +704,8 @@ def main():
         out = {
             "metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)",
             "value": patches / elapsed, "unit": "patches/s", "n_gpus": world,
+            "per_gpu_value": patches / elapsed / world,
+            "value_through_autograd_engine": world * B / (engine_ms_per_step * 1e-3),
             "value_single_stream": world * B / (one["ms_per_step"] * 1e-3),
             "value_two_streams_overlapped": world * B / (two["ms_per_step"] * 1e-3),
             "value_note": ("`value` = the timed region, every step on ONE stream (what a training loop, serialised by its "
@@ -732,6 +752,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "frac_single_launch": achieved_one / HBM_PEAK_GBPS,
+                         # flat copies of what the nested objects below hold (a line parser that keeps scalars keeps these)
+                         "valu_issue_frac": valu_issue["frac"] if valu_issue else None,
+                         "valu_issue_clock_GHz": valu_issue["clock_GHz_under_load"] if valu_issue else None,
+                         "valu_issue_wave_instr_per_launch": valu_issue["wave_instr_per_launch"] if valu_issue else None,
+                         "patches_per_s_through_autograd_engine": B / (engine_ms_per_step * 1e-3),
+                         "consistent_time_per_launch_le_ms_per_step": bool(share_ms <= ms_per_step * 1.0001),
+                         "sampled_pair_minus_time_per_launch_us": 1e3 * (one_kernel_avg - one_launch_ms),
                          "achieved_definition": ("algorithmic bytes per launch / time per launch in the timed region "
                                                  "(timed region / launches: launches on %d streams overlap)" % n_streams)
                                                 if n_streams > 1 else
@@ -748,10 +775,11 @@ def main():
                          "kernel_limited_patches_per_s": B / (share_ms * 1e-3),
                          "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
                          "kernel_ms_note": "event pairs around a SAMPLE of the launches (every 32nd of the timed region; for a region "
-                                           "shorter than 256 steps: every 16th of an untimed 128-step leg right after it): each pair "
-                                           "costs its stream an end-of-pipe bubble and reads ~10 % long on a back-to-back stream; "
+                                           "shorter than 256 steps: every 16th of an untimed 512-step leg right after it).  A pair on a "
+                                           "back-to-back stream spans the launch AND the ~3 us dispatch gap in front of it plus its own "
+                                           "end-of-pipe bubble, so it reads longer than time_per_launch_ms (and than ms_per_step); "
                                            "with N > 1 streams a launch overlaps its neighbours and exceeds time_per_launch_ms.  The "
-                                           "roofline is priced with time_per_launch_ms",
+                                           "roofline is priced with time_per_launch_ms (<= ms_per_step: consistent_... above)",
                          "launches_in_flight": n_streams,
                          "kernel_launches_timed": len(kernel_ms),
                          "algorithmic_bytes_per_launch": alg_bytes,

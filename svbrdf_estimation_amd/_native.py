@@ -163,6 +163,8 @@ class _on_device:
 
 def _dims(maps, scenes):
     """-> (B, S, H, W, shared): `scenes` is [B,S,9], or [S,9] = the same S scenes for every map (host tables only)"""
+    if not isinstance(scenes, torch.Tensor):
+        raise TypeError("scenes must be a torch.Tensor")
     if maps.dim() != 4 or maps.shape[1] != 12:
         raise ValueError("maps must be [B,12,H,W], got %s" % (tuple(maps.shape),))
     B, _, H, W = maps.shape
@@ -183,6 +185,9 @@ def _scene_table_for_launch(scenes, device):
     if scenes.dtype != torch.float32:
         raise TypeError("scenes must be float32 (got %s)" % scenes.dtype)
     if scenes.is_cuda:
+        if scenes.device != device:     # the raw pointer would be dereferenced by a kernel running on `device`
+            raise ValueError("scenes are on %s, the maps on %s: a device scene table must live with the maps"
+                             % (scenes.device, device))
         return (scenes if scenes.is_contiguous() else scenes.contiguous()), False
     rows = scenes.numel() // 9
     if rows <= host_scenes_max_rows():
@@ -467,7 +472,7 @@ _rings = {}
 def upload_scene_table(host_table, device):
     """[B,S,9] fp32 host tensor -> device tensor, without stalling the host on the stream."""
     if host_table.dtype != torch.float32:
-        host_table = host_table.float()
+        raise TypeError("scenes must be float32 (got %s)" % host_table.dtype)
     ring = _rings.get(device.index)
     if ring is None:
         ring = _rings[device.index] = _PinnedRing()

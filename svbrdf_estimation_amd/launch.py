@@ -101,3 +101,170 @@ def spawn_ranks(script, argv, world, timeout_s=None, poll_s=0.05, grace_s=10.0):
                 p.kill()
             p.wait()
     return worst
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rank -> CPU placement.  A rank drives its GPU with ~20 us of host work per 40 us loss step and feeds it through
+# DataLoader workers; on a two-socket node the GPU hangs off ONE socket's PCIe root, and a rank (or its workers, or its
+# pinned staging buffers) scheduled on the other socket pays the inter-socket hop on every launch and every upload.
+# Each rank therefore pins itself -- first thing, before any GPU call, no exec and no wrapper process -- to the CPUs of
+# its GPU's NUMA node; ranks whose GPUs share a node split that node's cores among themselves (SMT siblings stay
+# together), so that their worker pools do not compete.  Everything comes from sysfs; nothing here imports torch or
+# touches the GPU runtime.  When the topology cannot be read (no /sys/class/kfd, opaque *_VISIBLE_DEVICES values, a
+# device without a NUMA node) the rank is left where it is and says so.
+# ---------------------------------------------------------------------------------------------------------------------
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    cpus = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def format_cpulist(cpus):
+    cpus = sorted(set(cpus))
+    out, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else "%d-%d" % (cpus[i], cpus[j]))
+        i = j + 1
+    return ",".join(out)
+
+
+def _read(path):
+    with open(path) as f:
+        return f.read()
+
+
+def _visible_indices(value, n):
+    """an *_VISIBLE_DEVICES value as a list of indices into a list of n devices; None = not an index list"""
+    if value is None:
+        return list(range(n))
+    out = []
+    for tok in value.split(","):
+        tok = tok.strip()
+        if tok == "":
+            continue
+        if not tok.isdigit():
+            return None                      # UUID form (GPU-xxxx): not mapped here
+        if int(tok) >= n:
+            break                            # the runtimes stop at the first invalid index
+        out.append(int(tok))
+    return out
+
+
+def gpu_render_minors(sysfs="/sys", environ=None):
+    """DRM render minors of the GPUs in the order the HIP runtime numbers them, or None.  KFD topology nodes with
+    simd_count > 0 that this process may read (a device cgroup hides the others, as it hides them from the runtime),
+    in node order = ROCr's agent order; ROCR_VISIBLE_DEVICES then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES select
+    and reorder by index."""
+    environ = os.environ if environ is None else environ
+    base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        names = sorted((n for n in os.listdir(base) if n.isdigit()), key=int)
+    except OSError:
+        return None
+    minors = []
+    for n in names:
+        try:
+            props = dict(line.split(None, 1) for line in _read(os.path.join(base, n, "properties")).splitlines() if " " in line)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            minors.append(int(props.get("drm_render_minor", "-1")))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES" if "HIP_VISIBLE_DEVICES" in environ else "CUDA_VISIBLE_DEVICES"):
+        idx = _visible_indices(environ.get(var), len(minors))
+        if idx is None:
+            return None
+        minors = [minors[i] for i in idx]
+    return minors
+
+
+def _numa_node_of_minor(minor, sysfs):
+    try:
+        node = int(_read(os.path.join(sysfs, "class", "drm", "renderD%d" % minor, "device", "numa_node")).strip())
+    except (OSError, ValueError):
+        return None
+    return node if node >= 0 else None
+
+
+def _cores(cpus, sysfs):
+    """[[cpu, sibling, ...], ...]: the CPUs grouped by physical core, cores in ascending order"""
+    seen, cores = set(), []
+    for c in sorted(cpus):
+        if c in seen:
+            continue
+        try:
+            sib = [s for s in parse_cpulist(_read(os.path.join(sysfs, "devices", "system", "cpu", "cpu%d" % c, "topology",
+                                                                "thread_siblings_list"))) if s in cpus]
+        except (OSError, ValueError):
+            sib = [c]
+        sib = sorted(set(sib) | {c})
+        seen.update(sib)
+        cores.append(sib)
+    return cores
+
+
+def rank_cpu_placement(local_rank, local_world, share_device=False, sysfs="/sys", environ=None, allowed=None):
+    """Where local rank `local_rank` of `local_world` should run: {"cpus": [...], "numa_node": int or None,
+    "render_minor": int or None, "ranks_on_node": int, "source": str}.  `allowed` = the CPUs the process may use
+    (default: its current affinity mask)."""
+    allowed = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
+    unbound = {"cpus": allowed, "numa_node": None, "render_minor": None, "ranks_on_node": local_world}
+    minors = gpu_render_minors(sysfs, environ)
+    if not minors:
+        return dict(unbound, source="unbound: GPU topology not readable from sysfs")
+    device_of = (lambda r: 0) if share_device else (lambda r: r)
+    if device_of(local_world - 1) >= len(minors) or device_of(local_rank) >= len(minors):
+        return dict(unbound, source="unbound: %d local ranks but %d GPU(s) in the topology" % (local_world, len(minors)))
+    nodes = [_numa_node_of_minor(minors[device_of(r)], sysfs) for r in range(local_world)]
+    mine = nodes[local_rank]
+    if mine is None:
+        return dict(unbound, render_minor=minors[device_of(local_rank)], source="unbound: the GPU reports no NUMA node")
+    try:
+        node_cpus = set(parse_cpulist(_read(os.path.join(sysfs, "devices", "system", "node", "node%d" % mine, "cpulist"))))
+    except (OSError, ValueError):
+        return dict(unbound, render_minor=minors[device_of(local_rank)], source="unbound: node%d has no cpulist" % mine)
+    usable = node_cpus & set(allowed)
+    if not usable:
+        return dict(unbound, render_minor=minors[device_of(local_rank)],
+                    source="unbound: none of node%d's CPUs is in this process's affinity mask" % mine)
+    sharers = [r for r in range(local_world) if nodes[r] == mine]          # ranks whose GPU hangs off the same node
+    cores = _cores(usable, sysfs)
+    k, n = sharers.index(local_rank), len(sharers)
+    if len(cores) >= n:
+        lo, hi = k * len(cores) // n, (k + 1) * len(cores) // n
+        cpus = sorted(c for core in cores[lo:hi] for c in core)
+    else:                                                                  # more ranks than cores: share the node
+        cpus = sorted(usable)
+    return {"cpus": cpus, "numa_node": mine, "render_minor": minors[device_of(local_rank)], "ranks_on_node": n,
+            "source": "sysfs: renderD%d -> numa node %d, core slice %d of %d" % (minors[device_of(local_rank)], mine, k + 1, n)}
+
+
+def bind_rank_to_gpu_numa(local_rank, local_world, share_device=False):
+    """Pin the calling process (call it first thing in a rank, before any GPU call) as rank_cpu_placement says; returns
+    that record with "cpus" as a compact range string and "bound": whether the affinity mask was changed.
+    SVBRDF_NO_CPU_BINDING=1 leaves the process alone."""
+    if os.environ.get("SVBRDF_NO_CPU_BINDING"):
+        place = {"cpus": sorted(os.sched_getaffinity(0)), "numa_node": None, "render_minor": None,
+                 "ranks_on_node": local_world, "source": "unbound: SVBRDF_NO_CPU_BINDING is set"}
+    else:
+        place = rank_cpu_placement(local_rank, local_world, share_device)
+    bound = False
+    if place["numa_node"] is not None:
+        try:
+            os.sched_setaffinity(0, place["cpus"])
+            bound = True
+        except OSError as e:
+            place["source"] += " (sched_setaffinity failed: %s)" % e
+    place["n_cpus"] = len(place["cpus"])
+    place["cpus"] = format_cpulist(place["cpus"])
+    place["bound"] = bound
+    return place

@@ -12,7 +12,7 @@ tracer) goes through the generic per-scene loop built from that renderer's own o
 import torch
 import torch.nn as nn
 
-from . import _hostext, _native, environment, renderers, utils
+from . import _hostext, _native, _refcode, environment, renderers, utils
 
 
 class SVBRDFL1Loss(nn.Module):
@@ -50,15 +50,22 @@ class _FusedRenderingLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_loss):
+        if ctx.grads is None:
+            raise RuntimeError("Trying to backward through the fused rendering loss a second time: its gradient buffers "
+                               "were handed to the first backward.  Specify retain_graph=True for the first one.")
         grad_in, grad_tg = ctx.grads
         # chain rule through the scalar loss on the device (no host sync).  This is the FALLBACK host path (the native
-        # extension is the default: csrc/host_ext.cpp moves the buffer out and scales it in place unless
-        # retain_graph=True); here the buffers stay with the graph and every backward gets a scaled copy, so a second
-        # backward(retain_graph=True) works as it does through the reference's plain-autograd loss (losses.py:29-52).
+        # extension is the default and does the same in csrc/host_ext.cpp): a plain backward hands the kernel's buffers
+        # over and scales them in place -- no copy, no extra pass; under retain_graph=True they stay with the graph and
+        # every backward receives a scaled copy, so repeated backwards work as through the reference's plain-autograd
+        # loss (losses.py:29-52), and a second backward without it fails like autograd's own nodes do.
+        keep = torch._C._autograd._get_current_graph_task_keep_graph()
+        if not keep:
+            ctx.grads = None
         scale = grad_loss.detach().to(torch.float32).reshape(1)
         outs = []
         for g in (grad_in, grad_tg):
-            outs.append(None if g is None else _native.scale_inplace_(g.clone(), scale))
+            outs.append(None if g is None else _native.scale_inplace_(g.clone() if keep else g, scale))
         return outs[0], outs[1], None, None, None, None, None
 
 
@@ -126,15 +133,18 @@ class RenderingLoss(nn.Module):
         return self._forward_plugin(input, target)
 
     def uses_fused_kernel(self):
-        """True for this package's ``LocalRenderer`` -- and for the REFERENCE's own ``renderers.LocalRenderer`` object
-        (development/multiImage_pytorch/renderers.py:14), which is exactly what the kernels restate: a training script
-        that keeps the reference's renderer class (``install(patch_renderer=False)``) still gets the fused path.  Any
-        other object with ``.render`` (a path tracer, a subclass that overrides ``render``) takes the plugin loop."""
+        """True for this package's ``LocalRenderer`` -- and for an instance of the REFERENCE's own
+        ``renderers.LocalRenderer`` (development/multiImage_pytorch/renderers.py:14), which is exactly what the kernels
+        restate: a training script that keeps the reference's renderer class (``install(patch_renderer=False)``) still
+        gets the fused path.  "The reference's own" is decided by the class's CODE (``_refcode``: fingerprints of
+        ``dot_product``, ``normalize`` and the nine methods, recorded from the reference), never by its name: a fork
+        that edits ``renderers.py``, a subclass, an instance with a patched ``render`` -- any other object with
+        ``.render`` -- is a plugin and is rendered by calling it (``_forward_plugin``)."""
         r = self.renderer
         if isinstance(r, renderers.LocalRenderer):
-            return True
-        cls = type(r)
-        return cls.__name__ == "LocalRenderer" and cls.__module__ == "renderers" and cls.__mro__[1:] == (object,)
+            # a subclass (or an instance) that brings its own render() is a plugin like any other
+            return type(r).render is renderers.LocalRenderer.render and "render" not in vars(r)
+        return _refcode.is_reference_local_renderer(r)
 
     def _forward_fused(self, input, target, l1_weight=0.0, eps_l1=0.01, head=False):
         if head:

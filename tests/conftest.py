@@ -19,6 +19,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """the allowance ledger of this session (tests/tolerances.py): every use of a tolerance widening / tie exclusion, as
+    printed by the tests, in one file -- gpurun_out/ is what comes back from the GPU box"""
+    try:
+        import tolerances
+        if not tolerances.ALLOWANCES_USED:
+            return
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        import torch
+        where = torch.cuda.get_device_name(0) if torch.cuda.is_available() else "CPU only (oracle vs fixtures)"
+        with open(os.path.join(out, "tolerance_uses.txt"), "w") as f:
+            f.write("# allowance ledger of one pytest session (tests/tolerances.py); device: %s; exit status %s\n" % (where, exitstatus))
+            f.write("# what                                                 kind                     used of      total (cap)\n")
+            f.write("\n".join(tolerances.ledger_lines()) + "\n")
+    except Exception as e:      # a reporting aid must never turn a green run red
+        print("[tolerance] ledger not written: %r" % (e,))
+
+
 def pytest_collection_modifyitems(config, items):
     # GPU tests are selected with -m gpu; if someone runs them on a GPU-less box they must
     # fail loudly rather than skip (a silent skip would read as "parity green").

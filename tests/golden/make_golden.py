@@ -577,6 +577,14 @@ def g14_api():
                 entry[name] = {"kind": "function", "params": _params(obj)}
         public = sorted(k for k, v in vars(mod).items() if not k.startswith("_") and getattr(v, "__module__", None) == mod.__name__)
         api[mname] = {"in_scope": entry, "out_of_scope_names": [k for k in public if k not in names]}
+    # identity of the code the kernels restate (renderers.py:8-104): fingerprints of dot_product, normalize and the
+    # nine methods of LocalRenderer, computed by the product's own function from the imported reference.  The product
+    # takes the fused kernel for a foreign `renderers.LocalRenderer` object only when its class matches them.
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from svbrdf_estimation_amd import _refcode
+    fp = _refcode.fingerprint(ref_renderers.LocalRenderer)
+    api["renderers"]["code_identity"] = {"functions": list(_refcode.MODULE_FUNCTIONS) + list(_refcode.METHODS),
+                                         "source": fp["source"], "bytecode": {fp["python"]: fp["bytecode"]}}
     with open(os.path.join(HERE, "g14_api.json"), "w") as f:
         json.dump(api, f, indent=1, sort_keys=True)
     print("wrote g14_api.json")

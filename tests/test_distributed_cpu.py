@@ -125,6 +125,9 @@ def test_bench_gpus_n_spawns_n_ranks_without_a_launcher():
     assert len(lines) == 1, r.stdout
     assert lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == 2 and lines[0]["launch"] == "self-spawned"
     assert lines[0]["elapsed_max_over_ranks_s"] >= 0.02           # MAX over ranks: rank 1 sleeps 20 ms
+    # every rank reports where it runs (launch.bind_rank_to_gpu_numa; no GPU topology in this container: left unbound)
+    pr = lines[0]["per_rank"]
+    assert len(pr["cpus"]) == 2 and all(isinstance(c, str) and c for c in pr["cpus"]) and len(pr["cpu_binding"]) == 2
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():
@@ -209,3 +212,103 @@ def test_resume_accepts_both_checkpoint_layouts_and_counts_steps(tmp_path):
         assert ck["steps"] == before + 1
         back = models.convert_reference_state_dict(ck["model_state_dict"])
         assert all(torch.equal(back[k], v) for k, v in net.state_dict().items())       # lr 0: the weights are the loaded ones
+
+
+def _fake_sysfs(root, gpus, nodes, readable=None):
+    """a sysfs tree shaped like the MI355X node the GPU boxes are slots of: KFD topology nodes 0..1 = CPU sockets, then one
+    node per GPU (drm_render_minor 128 + 8 i); `gpus` = the NUMA node of each; `nodes` = {numa node: cpulist};
+    `readable` = indices of the GPUs whose KFD properties this process may read (a device cgroup hides the others)."""
+    def put(rel, text):
+        path = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text)
+    for n in range(2):
+        put("class/kfd/kfd/topology/nodes/%d/properties" % n, "cpu_cores_count 128\nsimd_count 0\ndrm_render_minor 0\n")
+    for i, numa in enumerate(gpus):
+        minor = 128 + 8 * i
+        if readable is None or i in readable:
+            put("class/kfd/kfd/topology/nodes/%d/properties" % (2 + i),
+                "cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor %d\nunique_id %d\n" % (minor, 1000 + i))
+        else:
+            os.makedirs(os.path.join(root, "class/kfd/kfd/topology/nodes/%d" % (2 + i)), exist_ok=True)   # no properties
+        put("class/drm/renderD%d/device/numa_node" % minor, "%d\n" % numa)
+    from svbrdf_estimation_amd import launch
+    for numa, cpulist in nodes.items():
+        put("devices/system/node/node%d/cpulist" % numa, cpulist + "\n")
+        cpus = launch.parse_cpulist(cpulist)
+        half = len(cpus) // 2
+        for k, c in enumerate(cpus):                    # SMT: the second half of a node's list are the siblings of the first
+            sib = sorted((c, cpus[(k + half) % len(cpus)]))
+            put("devices/system/cpu/cpu%d/topology/thread_siblings_list" % c, "%d,%d\n" % tuple(sib))
+
+
+def test_rank_cpu_placement_follows_the_gpu_numa_node(tmp_path):
+    """launch.rank_cpu_placement on a fake sysfs of the two-socket, eight-GPU node (GPUs 0-3 on node 0, 4-7 on node 1;
+    256 CPUs, SMT siblings c and c + 128): every rank lands on ITS GPU's socket, ranks of one socket get disjoint
+    16-core slices with both SMT siblings, together exactly the socket; *_VISIBLE_DEVICES and a device cgroup that
+    hides the other GPUs are honoured; opaque settings leave the rank unbound rather than misplaced."""
+    from svbrdf_estimation_amd import launch
+    root = str(tmp_path / "sys")
+    nodes = {0: "0-63,128-191", 1: "64-127,192-255"}
+    _fake_sysfs(root, [0, 0, 0, 0, 1, 1, 1, 1], nodes)
+    allowed = list(range(256))
+    assert launch.gpu_render_minors(root, {}) == [128 + 8 * i for i in range(8)]
+    places = [launch.rank_cpu_placement(r, 8, sysfs=root, environ={}, allowed=allowed) for r in range(8)]
+    assert [p["numa_node"] for p in places] == [0] * 4 + [1] * 4 and all(p["ranks_on_node"] == 4 for p in places)
+    for node, ranks in ((0, range(0, 4)), (1, range(4, 8))):
+        sets = [set(places[r]["cpus"]) for r in ranks]
+        assert all(len(s) == 32 for s in sets)                                   # 16 cores x 2 threads
+        assert all(a.isdisjoint(b) for i, a in enumerate(sets) for b in sets[i + 1:])
+        assert set().union(*sets) == set(launch.parse_cpulist(nodes[node]))
+        assert all((c + 128 in s) == (c < 128) or c >= 128 for s in sets for c in s if c < 128)   # siblings stay together
+    assert places[0]["cpus"][:3] == [0, 1, 2] and 128 in places[0]["cpus"] and places[5]["render_minor"] == 168
+    # one rank alone on its socket gets the whole socket; two ranks sharing ONE device split its socket
+    assert len(launch.rank_cpu_placement(0, 1, sysfs=root, environ={}, allowed=allowed)["cpus"]) == 128
+    a = launch.rank_cpu_placement(0, 2, share_device=True, sysfs=root, environ={}, allowed=allowed)
+    b = launch.rank_cpu_placement(1, 2, share_device=True, sysfs=root, environ={}, allowed=allowed)
+    assert a["numa_node"] == b["numa_node"] == 0 and set(a["cpus"]).isdisjoint(b["cpus"]) and len(a["cpus"]) == len(b["cpus"]) == 64
+    # ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES select and reorder by index (HIP indexes ROCr's visible list)
+    assert launch.gpu_render_minors(root, {"ROCR_VISIBLE_DEVICES": "5,1"}) == [168, 136]
+    assert launch.gpu_render_minors(root, {"ROCR_VISIBLE_DEVICES": "5,1", "HIP_VISIBLE_DEVICES": "1"}) == [136]
+    assert launch.rank_cpu_placement(0, 1, sysfs=root, environ={"ROCR_VISIBLE_DEVICES": "6"}, allowed=allowed)["numa_node"] == 1
+    # the GPU boxes: only the slot's GPU is readable in the KFD topology, and it is device 0 whatever its position
+    root2 = str(tmp_path / "sys2")
+    _fake_sysfs(root2, [0, 0, 0, 0, 1, 1, 1, 1], nodes, readable=[7])
+    p = launch.rank_cpu_placement(0, 1, sysfs=root2, environ={"ROCR_VISIBLE_DEVICES": "0", "HIP_VISIBLE_DEVICES": "0"}, allowed=allowed)
+    assert p["render_minor"] == 184 and p["numa_node"] == 1 and launch.format_cpulist(p["cpus"]) == "64-127,192-255"
+    # an affinity mask narrower than the socket is respected; UUIDs, missing topology, more ranks than GPUs: unbound
+    narrow = launch.rank_cpu_placement(0, 1, sysfs=root, environ={}, allowed=range(0, 8))
+    assert narrow["cpus"] == list(range(8)) and narrow["numa_node"] == 0
+    for env, world in (({"ROCR_VISIBLE_DEVICES": "GPU-abcdef"}, 1), ({}, 9)):
+        u = launch.rank_cpu_placement(0, world, sysfs=root, environ=env, allowed=allowed)
+        assert u["numa_node"] is None and u["cpus"] == allowed and u["source"].startswith("unbound")
+    assert launch.rank_cpu_placement(0, 1, sysfs=str(tmp_path / "nothing"), environ={}, allowed=allowed)["numa_node"] is None
+
+
+def test_bind_rank_pins_the_process_and_reports_a_cpulist(tmp_path):
+    """bind_rank_to_gpu_numa in a child process (so that this suite's own affinity is untouched): with a readable
+    topology the affinity mask becomes the slice; without one it stays; both report compact cpulists."""
+    import json
+    import subprocess
+    root = str(tmp_path / "sys")
+    have = sorted(os.sched_getaffinity(0))
+    if len(have) < 2:
+        pytest.skip("needs two CPUs")
+    _fake_sysfs(root, [0, 0], {0: "%d-%d" % (have[0], have[-1])})
+    code = ("import json, os, sys; sys.path.insert(0, %r)\n"
+            "from svbrdf_estimation_amd import launch\n"
+            "real = launch.rank_cpu_placement\n"
+            "launch.rank_cpu_placement = lambda r, w, s=False: real(r, w, s, sysfs=%r, environ={})\n"
+            "p = launch.bind_rank_to_gpu_numa(1, 2)\n"
+            "print(json.dumps({'p': p, 'now': sorted(os.sched_getaffinity(0))}))\n" % (ROOT, root))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    from svbrdf_estimation_amd import launch
+    assert out["p"]["bound"] and out["p"]["numa_node"] == 0 and launch.parse_cpulist(out["p"]["cpus"]) == out["now"]
+    assert 0 < len(out["now"]) < len(have) and set(out["now"]) <= set(have) and out["p"]["n_cpus"] == len(out["now"])
+    env = dict(os.environ, SVBRDF_NO_CPU_BINDING="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert not out["p"]["bound"] and out["now"] == have

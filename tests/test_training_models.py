@@ -89,3 +89,25 @@ def test_tiled_png_round_trip(tmp_path):
         data.read_tiled_png(path, 3)
     syn = data.SyntheticSvbrdfDataset(4, image_size=8, seed=1)
     assert len(syn) == 4 and syn[2]["svbrdf"].shape == (12, 8, 8) and torch.equal(syn[2]["svbrdf"], syn[2]["svbrdf"])
+
+
+def test_in_tree_miopen_cache_is_what_its_manifest_says():
+    """tests/test_gpu_parity.py's at-size configs[3] harness test takes 1 s with the in-tree MIOpen user cache and
+    ~5 min (compiling) without: the cache is tracked, and its MANIFEST.json (file hashes, MIOpen build, provenance:
+    tools/miopen_cache_manifest.py) must describe the files that are there; train.py prints the manifest's sha256."""
+    import hashlib
+    import json
+    from svbrdf_estimation_amd import training
+    here = os.path.join(os.path.dirname(os.path.abspath(training.__file__)), "miopen_cache")
+    with open(os.path.join(here, "MANIFEST.json")) as f:
+        man = json.load(f)
+    assert man["arch"] == "gfx950" and man["produced_by"] and man["miopen_build"] and len(man["files"]) >= 2
+    on_disk = sorted(os.path.relpath(os.path.join(r, n), here) for r, _, ns in os.walk(here) for n in ns if n != "MANIFEST.json")
+    assert on_disk == sorted(man["files"])
+    for rel, want in man["files"].items():
+        with open(os.path.join(here, rel), "rb") as f:
+            raw = f.read()
+        assert len(raw) == want["bytes"] and hashlib.sha256(raw).hexdigest() == want["sha256"], rel
+    ident = training.miopen_cache_identity(here)
+    assert ident["in_tree"] and ident["files_match_manifest"] and len(ident["manifest_sha256"]) == 64
+    assert training.miopen_cache_identity(None) == {"in_tree": False, "note": "the user's / MIOpen's default cache"}

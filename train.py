@@ -113,6 +113,9 @@ def parse_args(argv=None):
                          "and ONE scene stream (every rank seeds alike and skips the draws that belong to the other ranks' "
                          "items) -- and writes rank 0's gradient after the first backward (DDP-averaged) and the global "
                          "loss to this file")
+    ap.add_argument("--no-ddp-probe", action="store_true",
+                    help="skip the eight untimed steps after the timed region that time loss.backward() with and without "
+                         "DDP's all-reduce (multi-rank GPU runs only)")
     ap.add_argument("--phase-times", action="store_true",
                     help="bracket the phases of every timed step (dataloader wait on the host clock; upload + input "
                          "synthesis, network forward, loss, backward, optimizer with HIP events) and report their means: "
@@ -129,16 +132,28 @@ def run(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))      # ranks on THIS node (multi-node: world > local_world)
     if args.gpus and args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (or run train.py without a rank "
                          "environment and let it spawn them)" % (args.gpus, world))
     on_gpu = args.device == "cuda"
+    # first thing in a rank, before any GPU call: pin it (and the DataLoader workers it will fork) to the CPUs next to its
+    # GPU, ranks on one socket splitting that socket's cores (launch.py)
+    from svbrdf_estimation_amd import launch
+    placement = launch.bind_rank_to_gpu_numa(local_rank, local_world, args.share_device) if on_gpu else \
+        {"cpus": launch.format_cpulist(os.sched_getaffinity(0)), "n_cpus": len(os.sched_getaffinity(0)), "numa_node": None,
+         "source": "unbound: --device cpu", "bound": False}
     if on_gpu:
         assert torch.cuda.is_available(), "no ROCm device visible"
         if args.share_device:
             local_rank = 0
-        elif torch.cuda.device_count() < world:
-            raise SystemExit("%d ranks but only %d device(s) visible" % (world, torch.cuda.device_count()))
+            if world > 1 and (args.backend or "nccl") == "nccl":
+                # RCCL refuses two ranks on one device (and would hang in init or the first collective before saying so)
+                if args.backend == "nccl":
+                    raise SystemExit("--share-device puts every rank on cuda:0, which RCCL does not support: use --backend gloo")
+                args.backend = "gloo"
+        elif torch.cuda.device_count() <= local_rank:
+            raise SystemExit("local rank %d but only %d device(s) visible on this node" % (local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     else:
@@ -169,7 +184,7 @@ def run(args):
     # per-rank scene RNG -- or, for --verify-global-batch, one stream shared by all ranks (each skips the others' draws)
     utils.enable_deterministic_random_engine(args.seed if verify else distributed.rank_seed(args.seed, rank))
     if on_gpu:      # the rank's own CPU work is tiny (scene sampler, collation): a big intra-op pool only spins (bench.py main)
-        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
+        torch.set_num_threads(max(1, min(8, placement["n_cpus"])))
     decode = not args.fused_head
     if args.model == "multi":
         net = models.MultiViewModel(use_coords=not args.no_coords, decode=decode)
@@ -183,8 +198,12 @@ def run(args):
     hybrid = conv_mode in ("hybrid", "auto") and on_gpu
     auto = conv_mode == "auto" and on_gpu
     # auto: forward under the reference's flags at steps 0-1, under the immediate-mode choice at steps 2-3 (the first of
-    # each pair compiles, the second is timed with HIP events); from step 4 on the faster of the two
+    # each pair compiles, the second is timed with HIP events); from step 4 on the faster of the two.  The four
+    # calibration steps are EXTRA untimed steps in front of the warm-up (they carry two device synchronisations and two
+    # steps under the slower setting: never part of `value`, whatever --warmup says), and the ranks agree on the choice:
+    # the timings are MAX-reduced over the ranks before they are compared.
     forward_flag, calib = True, {}
+    calib_steps = 4 if auto else 0
     steps_done = 0
     if args.resume:
         ck = torch.load(args.resume, map_location="cpu", weights_only=False)
@@ -218,10 +237,10 @@ def run(args):
         loss_fn.rendering_loss.random_configuration_count = args.random_scenes
         loss_fn.rendering_loss.specular_configuration_count = args.specular_scenes
 
-    total_steps = args.warmup + args.steps
-    if args.workers < 0:
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        args.workers = max(2, min(16, (os.cpu_count() or 2) // max(1, local_world) - 1))
+    total_steps = calib_steps + args.warmup + args.steps
+    if args.workers < 0:        # the rank's CPU set is its share of the node already (placement), else split the host
+        mine = placement["n_cpus"] if placement.get("bound") else (os.cpu_count() or 2) // max(1, local_world)
+        args.workers = max(2, min(16, mine - 1))
     device_source = args.data == "synthetic" and on_gpu and not verify
     if device_source:
         dataset, args.workers = None, 0
@@ -269,14 +288,31 @@ def run(args):
         e.record()
         return e
 
-    losses_seen, t0, it = [], None, batches()
+    # after the timed region, DDP runs only: the same backward WITH the bucketed all-reduce (DDP's hooks launch a bucket's
+    # all-reduce on RCCL's stream as soon as its gradients exist, overlapping the rest of the backward) and WITHOUT it
+    # (model.no_sync()), alternating, HIP events around loss.backward() -- what the all-reduce of ~320 MB costs a step
+    # beyond the backward it hides behind.  No optimizer step in these (no_sync gradients are rank-local).
+    probe_steps = 8 if (grouped and on_gpu and not verify and not args.no_ddp_probe) else 0
+    end_timed = total_steps
+    total_steps += probe_steps
+    probe_ms = {True: [], False: []}
+    import contextlib
+    losses_seen, t0, elapsed, it = [], None, None, batches()
     for step in range(total_steps):
-        if step == args.warmup:
+        if step == calib_steps + args.warmup:
             if on_gpu:
                 torch.cuda.synchronize(dev)
             if grouped:
                 barrier()
             t0 = time.perf_counter()
+        if step == end_timed:
+            if on_gpu:
+                torch.cuda.synchronize(dev)
+            if grouped:
+                barrier()
+            elapsed = time.perf_counter() - t0
+        probing = step >= end_timed
+        synced = not (probing and (step - end_timed) % 2 == 1)
         t_wait = time.perf_counter()
         batch = next(it)
         t_wait = time.perf_counter() - t_wait
@@ -297,6 +333,10 @@ def run(args):
             if step < 4:
                 forward_flag = step < 2
             elif step == 4 and len(calib) == 2:
+                if grouped:     # one choice for the whole job: the slowest rank's timing of each setting decides
+                    both = torch.tensor([calib[True], calib[False]], dtype=torch.float64, device=dev if nccl else "cpu")
+                    dist.all_reduce(both, op=dist.ReduceOp.MAX)
+                    calib = {True: float(both[0]), False: float(both[1])}
                 forward_flag = calib[True] <= calib[False]
             probe = (mark(), None) if step in (1, 3) else None
         if hybrid:
@@ -319,7 +359,17 @@ def run(args):
                 loss_fn.rendering_loss.sample_scene_table((world - 1 - rank) * args.batch)
         if timing:
             marks.append(mark())
-        loss.backward()
+        if probing:
+            bw0 = mark()
+        with (contextlib.nullcontext() if synced else model.no_sync()):
+            loss.backward()
+        if probing:
+            bw1 = mark()
+            torch.cuda.synchronize(dev)
+            if step - end_timed >= 2:                    # the first pair warms the no_sync path up
+                probe_ms[synced].append(bw0.elapsed_time(bw1))
+            optimizer.zero_grad(set_to_none=True)
+            continue
         if verify and step == 0:
             g_loss = distributed.global_mean(loss.detach() if (nccl or not grouped) else loss.detach().cpu()).item()
             if rank == 0:
@@ -335,7 +385,7 @@ def run(args):
         if timing:
             marks.append(mark())
             torch.cuda.synchronize(dev)
-            if step >= args.warmup:
+            if step >= calib_steps + args.warmup:
                 phase_ms["data_wait"].append(1e3 * t_wait)
                 for name, a, b in zip(phases[1:], marks[:-1], marks[1:]):
                     phase_ms[name].append(a.elapsed_time(b))
@@ -343,11 +393,23 @@ def run(args):
         torch.cuda.synchronize(dev)
     if grouped:
         barrier()
-    elapsed = time.perf_counter() - t0
+    if elapsed is None:
+        elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
+    per_rank = {"elapsed_s": [own_elapsed], "cpus": [placement["cpus"]], "numa_node": [placement["numa_node"]],
+                "cpu_binding": [placement["source"]]}
     if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        every = [None] * dist.get_world_size()
+        dist.all_gather_object(every, {"elapsed_s": own_elapsed, "cpus": placement["cpus"], "numa_node": placement["numa_node"],
+                                       "cpu_binding": placement["source"],
+                                       "backward_ms": {("with_allreduce" if k else "no_sync"): (sum(v) / len(v) if v else None)
+                                                       for k, v in probe_ms.items()}})
+        per_rank = {k: [e[k] for e in every] for k in every[0]}
+    per_rank["ms_per_step"] = [1e3 * e / args.steps for e in per_rank["elapsed_s"]]
+    per_rank["patches_per_s"] = [args.batch * args.steps / e for e in per_rank["elapsed_s"]]
     vals = torch.stack(losses_seen).float()
     if grouped and not nccl:
         vals = vals.cpu()
@@ -355,7 +417,8 @@ def run(args):
     first, last = distributed.global_mean(first).item(), distributed.global_mean(last).item()
     result = {"metric": "end-to-end training patches/s (U-Net + %s loss)" % args.loss,
               "value": world * args.batch * args.steps / elapsed, "unit": "patches/s", "n_gpus": world,
-              "ranks_seen": dist.get_world_size() if grouped else 1,
+              "per_gpu_value": args.batch * args.steps / elapsed,
+              "ranks_seen": dist.get_world_size() if grouped else 1, "per_rank": per_rank,
               "process_group": ("%s, world size %d, DistributedDataParallel" % (backend, dist.get_world_size())) if grouped else None,
               "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps, "warmup": args.warmup,
               "loss_first_quarter": first, "loss_last_quarter": last,
@@ -363,7 +426,17 @@ def run(args):
                          "scenes": args.random_scenes + args.specular_scenes, "fused_head": bool(args.fused_head),
                          "data": ("synthetic (device)" if device_source else args.data) if args.data.startswith("synthetic") else "tiled-png",
                          "workers": args.workers, "conv_mode": conv_mode, "channels_last": bool(args.channels_last),
-                         "miopen_cache": "in-tree" if miopen_cache else "the user's / MIOpen's default"}}
+                         "miopen_cache": training.miopen_cache_identity(miopen_cache)}}
+    if len(vals) <= 64:         # short runs (tests): every step's own loss, calibration and warm-up steps included
+        result["loss_per_step"] = [float(v) for v in vals.tolist()]
+        result["untimed_leading_steps"] = calib_steps + args.warmup
+    if probe_steps:
+        w, n = probe_ms[True], probe_ms[False]
+        result["ddp_backward_probe"] = {
+            "backward_ms_with_allreduce": sum(w) / len(w), "backward_ms_no_sync": sum(n) / len(n), "samples_each": len(w),
+            "note": "rank 0, untimed steps after the timed region, HIP events around loss.backward(): DDP's bucketed "
+                    "all-reduce (gradient_as_bucket_view, 25 MB buckets) against model.no_sync(); the difference is what the "
+                    "all-reduce of the U-Net's gradients costs a step beyond the backward it overlaps with"}
     if auto:
         result["config"]["conv_forward"] = {"chosen": "reference flags" if forward_flag else "immediate mode",
                                             "calibration_ms": {("reference flags" if k else "immediate mode"): v for k, v in calib.items()}}
