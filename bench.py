@@ -755,6 +755,9 @@ def main():
                          # flat copies of what the nested objects below hold (a line parser that keeps scalars keeps these)
                          "valu_issue_frac": valu_issue["frac"] if valu_issue else None,
                          "valu_issue_clock_GHz": valu_issue["clock_GHz_under_load"] if valu_issue else None,
+                         # boxes (and builds: the chip lowers its clock as the issue stream gets denser) differ in clock by
+                         # 5-15 %; launch duration x the clock measured in this run is the box-independent figure
+                         "shader_cycles_per_launch": (share_ms * 1e-3 * clock_ghz * 1e9) if clock_ghz else None,
                          "valu_issue_wave_instr_per_launch": valu_issue["wave_instr_per_launch"] if valu_issue else None,
                          "patches_per_s_through_autograd_engine": B / (engine_ms_per_step * 1e-3),
                          "consistent_time_per_launch_le_ms_per_step": bool(share_ms <= ms_per_step * 1.0001),

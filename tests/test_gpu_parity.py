@@ -528,12 +528,15 @@ def test_config2_full_size_properties_and_all_8_items_vs_oracle(dev, native, ora
     # (7) the oracle, item by item (per-item loss) and on the whole batch (gradient with the fp64 widening and the tie map)
     oracle.set_threads(min(32, os.cpu_count() or 1))
     for b in range(B):
-        lo, go = oracle.rendering_loss(inp[b:b + 1], tgt[b:b + 1], table[b:b + 1])
+        lo, _ = oracle.rendering_loss(inp[b:b + 1], tgt[b:b + 1], table[b:b + 1])
         assert_loss_close(per_item[b], lo, "config-2 item %d vs oracle" % b)
-        assert_grad_close(_np(grad[b:b + 1]) * B, go, "config-2 item %d grad vs oracle" % b)
     ref_l, ref_g = oracle.rendering_loss(inp, tgt, table)
+    _, g64 = oracle.rendering_loss(inp, tgt, table, f64=True)
     assert_loss_close(loss.item(), ref_l, "config-2 batch loss vs oracle")
-    assert_grad_close(_np(grad), ref_g, "config-2 batch grad vs oracle")
+    # every gradient element of all 8 items; expected ties ~ 2e-6 per (pixel, scene, channel) term, as at config 5
+    n_terms = B * H * H * table.shape[1] * 3
+    assert_grad_close(_np(grad), ref_g, "config-2 gradient, all 8 items", f64=g64, tie_map=oracle.loss_tie_map(inp, tgt, table),
+                      max_ties=max(8, int(2e-6 * n_terms)), max_widened=max(8, int(2e-6 * grad.numel())))
 
 
 def test_config5_per_gpu_shape_512_32_scenes_batch_8_vs_oracle(dev, native, oracle):
@@ -557,8 +560,9 @@ def test_config5_per_gpu_shape_512_32_scenes_batch_8_vs_oracle(dev, native, orac
     _, g64 = oracle.mixed_loss(inp, tgt, table, 0.1, f64=True)
     assert_loss_close(loss.item(), ref_l, "config-5 mixed loss")
     # expected ties ~ 2e-6 per (pixel, scene, channel) term; measured 0.6e-6 (31 of 524288 pixels at 512x512, 32 scenes); the cap allows 2e-6
-    assert_grad_close(_np(x.grad), ref_g, "config-5 gradient", f64=g64, tie_map=oracle.loss_tie_map(inp, tgt, table),
-                      max_ties=max(8, int(2e-6 * inp.shape[0] * inp.shape[2] * inp.shape[3] * table.shape[1] * 3)))
+    assert_grad_close(_np(x.grad), ref_g, "config-5 gradient, all 8 items", f64=g64, tie_map=oracle.loss_tie_map(inp, tgt, table),
+                      max_ties=max(8, int(2e-6 * inp.shape[0] * inp.shape[2] * inp.shape[3] * table.shape[1] * 3)),
+                      max_widened=max(8, int(2e-6 * inp.size)))
 
 
 # ---------------------------------------------------------------- plugin interface (renderers.py:67)

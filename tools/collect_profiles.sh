@@ -31,6 +31,11 @@ for c in ${CASES:-k1 k2 k4 k3_mixed k3_head k3_head_l1 k3_untied k3_config4 k3_c
   # the raw per-dispatch traces are large: keep the stats and the counter tables only
   find $OUT/${TAG}_case_${c}_stats $OUT/${TAG}_case_${c}_fetch $OUT/${TAG}_case_${c}_write -name '*_kernel_trace.csv' -delete 2>/dev/null
 done
+# VALU instruction counts of the K3 shapes the headline does not run (their VALU-issue fraction: DESIGN.md section 4)
+for c in ${SQ_CASES:-k3_untied k3_config4 k3_config5}; do
+  timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_WAVES -d $OUT/${TAG}_case_${c}_sq --output-format csv -- python3 $R/tools/kernel_cases.py $c 12 >> $OUT/${TAG}_case_${c}.log 2>&1
+  find $OUT/${TAG}_case_${c}_sq -name '*_kernel_trace.csv' -delete 2>/dev/null
+done
 cd $R
 # un-profiled bench line (with the CPU baseline) -- never compare profiled and un-profiled timings
 timeout 400 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err

@@ -19,6 +19,7 @@ static decltype(&svbrdf_rendering_loss_workspace_bytes) p_ws_bytes;
 static decltype(&svbrdf_mixed_loss_fwd_bwd_host_scenes) p_loss, p_head;
 static decltype(&svbrdf_last_error) p_last_error;
 static decltype(&svbrdf_scale_inplace) p_scale;
+static decltype(&svbrdf_debug_clock_probe) p_clock;
 #define svbrdf_make_xrow p_make_xrow
 #define svbrdf_rendering_loss_workspace_bytes p_ws_bytes
 #define svbrdf_mixed_loss_fwd_bwd_host_scenes p_loss
@@ -40,6 +41,7 @@ int main()
     p_last_error = (decltype(p_last_error))dlsym(h, "svbrdf_last_error");
     p_head = (decltype(p_head))dlsym(h, "svbrdf_head_loss_fwd_bwd_host_scenes");
     p_scale = (decltype(p_scale))dlsym(h, "svbrdf_scale_inplace");
+    p_clock = (decltype(p_clock))dlsym(h, "svbrdf_debug_clock_probe");
     const bool head = std::getenv("K3_HEAD") != nullptr;       // input = [B,9,H,W] encoded head output
     if (head) p_loss = p_head;
     if (!p_make_xrow || !p_ws_bytes || !p_loss || !p_last_error) { std::printf("missing symbols in %s\n", libpath); return 1; }
@@ -137,8 +139,25 @@ int main()
                 const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / steps;
                 if (us < best) best = us;
             }
+            // the shader clock the chip holds under this mode's loop (K3_CLOCK=1): a one-wave probe kernel spins 3 ms on a
+            // stream of its own (s_memtime against the constant 100 MHz s_memrealtime) while the loop keeps running
+            double ghz = 0.0;
+            if (std::getenv("K3_CLOCK") && p_clock && m.parts > 0 && !m.join) {
+                unsigned long long *d_probe, h_probe[2] = {0, 0};
+                CK(hipMalloc(&d_probe, 16)); CK(hipMemset(d_probe, 0, 16));
+                CA(p_clock(d_probe, 300000ULL, st[NS - 1]));
+                const auto c0 = std::chrono::steady_clock::now();
+                int i = 0;
+                while (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count() < 4.5)
+                    for (int k = 0; k < 16; ++k, ++i) CA(launch(0, 1, m.alternate ? (i & 1) : 0));
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(h_probe, d_probe, 16, hipMemcpyDeviceToHost));
+                if (h_probe[1]) ghz = (double)h_probe[0] / (double)h_probe[1] * 0.1;
+                CK(hipFree(d_probe));
+            }
             float lossv = 0.0f;
             CK(hipMemcpy(&lossv, d_loss, 4, hipMemcpyDeviceToHost));
+            if (ghz > 0.0) std::printf("clock %.3f GHz  cycles/launch %.0f  ", ghz, best * 1e-6 * ghz * 1e9);
             std::printf("round %d  %-48s %7.2f us/step  %8.0f patches/s   loss %.7f\n", round, m.name, best, B / (best * 1e-6), lossv);
             std::fflush(stdout);
         }

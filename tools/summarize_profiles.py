@@ -93,6 +93,18 @@ for log in sorted(glob.glob(os.path.join(G, "%s_case_*.log" % tag))):
                  if kern in r["Kernel_Name"] and r["Counter_Name"] == counter]
             if v:
                 row[counter + "_KiB_raw_mean"] = sum(v) / len(v)
+    sq = one("%s_case_%s_sq/*/*_counter_collection.csv" % (tag, c))
+    if sq:
+        for counter, key in (("SQ_INSTS_VALU", "valu_wave_instr_per_launch"), ("SQ_INSTS_VALU_TRANS_F32", "trans_wave_instr_per_launch")):
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(sq)) if kern in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if v:
+                row[key] = sum(v) / len(v)
+        clock = (((bench or {}).get("roofline") or {}).get("valu_issue") or {}).get("clock_GHz_under_load")
+        if clock and "valu_wave_instr_per_launch" in row and "avg_us" in row:
+            # SIMD issue peak: one wave64 VALU instruction per 2 cycles per SIMD, 1024 SIMDs (MI355X_MICROARCH.md), at the
+            # shader clock bench.py measured under the config-2 loop of the same collection run
+            row["valu_issue_frac"] = row["valu_wave_instr_per_launch"] / (row["avg_us"] * 1e-6) / (1024 * clock * 1e9 / 2.0)
+            row["valu_issue_clock_GHz_assumed"] = clock
     if "FETCH_SIZE_KiB_raw_mean" in row and "WRITE_SIZE_KiB_raw_mean" in row:
         row["read_bytes_x2_corrected"] = 2.0 * row["FETCH_SIZE_KiB_raw_mean"] * 1024.0
         row["write_bytes"] = row["WRITE_SIZE_KiB_raw_mean"] * 1024.0
