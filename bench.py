@@ -404,6 +404,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (or let bench.py spawn them: run it "
                          "without a rank environment)" % (args.gpus, world))
     # first thing in a rank, before any GPU call: pin it to the CPUs next to its GPU (launch.py)
+    host_cpus = os.sched_getaffinity(0)         # the CPU baseline leg gets the whole host back
     placement = launch.bind_rank_to_gpu_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), args.share_device)
     if args.plumbing_only:
         return plumbing_only(args, rank, world, placement)
@@ -803,6 +804,7 @@ def main():
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_kernels(dev, H)
         if world == 1 and not args.no_cpu_baseline:
+            os.sched_setaffinity(0, host_cpus)      # "the host cores of the box", not the GPU's socket only
             table = loss_fn.sample_scene_table(B)
             out["cpu_baseline"] = cpu_baseline(args, inp_h, tgt_h, table)
         else:

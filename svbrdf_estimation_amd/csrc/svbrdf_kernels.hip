@@ -13,8 +13,9 @@
 //     pixel coords -> wo, wi -> h -> NH, VN, LN -> 1-NH^2
 // reproduces the reference's fp32 rounding sequence exactly: products rounded one by one
 // (-ffp-contract=off, no FMA contraction), dot products summed (p0+p1)+p2 like
-// torch.sum(dim=-3), correctly rounded sqrt and division.  Downstream of those values the
-// computation is well conditioned.
+// torch.sum(dim=-3), correctly rounded sqrt and division.  Downstream of those values -- and
+// for the three dot products that do not feed NH (n.wo, n.wi, wo.h: SVBRDF_FMA_VN_LN) -- the
+// computation is well conditioned and uses explicit FMAs and 1-ULP primitives.
 //
 // Data layout.  Maps stay in the reference's BCHW planar layout (W contiguous): lane l of a
 // wave owns VEC horizontally adjacent pixels (K1/K2: VEC in {1,2,4}; K3: one pixel), so each
@@ -114,6 +115,28 @@ __device__ __forceinline__ float log2_(float x) { return SVBRDF_ABLATE == 8 ? x 
 #ifndef SVBRDF_K3_PEEL_LAST
 #define SVBRDF_K3_PEEL_LAST 0      // 1: the last render of a wave is shaded without the (unused) geometry of a successor
 #endif
+// The exact-rounding contract (header of this file) covers the path into NH -- coords, wo, wi, h, n.h, 1 - NH^2 -- because the
+// GGX denominator amplifies NH's last bit by 1e3..1e4.  n.wo, n.wi and wo.h feed only well-conditioned terms (Smith G, the
+// cosine factor, Fresnel): a last-bit difference there moves a radiance by ~1e-7 relative, a hundredth of the 1e-5 bound.
+// They are one multiply + two FMAs instead of the reference's three rounded products and two adds: -10 VALU per render
+// (K3 at config 2: -2 % time, same-box A/B profiles/r04_k3_ab_algebra.txt).  0 restores the op-by-op form (A/B builds).
+#ifndef SVBRDF_FMA_VN_LN
+#define SVBRDF_FMA_VN_LN 1
+#endif
+// The 1/pi of the diffuse gradient and dA/dr_hat = 4 r^3 of the roughness gradient are per-pixel constants: applied once
+// after the scene loop instead of once per render and channel (-6 VALU per render; -1.5 % time in the same A/B).
+#ifndef SVBRDF_K3_DEFER_SCALES
+#define SVBRDF_K3_DEFER_SCALES 1
+#endif
+// f = (1-F) d/pi + F GD (renderers.py:18-20, 62-65) evaluated as d/pi + F (GD - d/pi): the difference is shared with the
+// adjoint's d f/d F, -6 VALU per render (-0.5 ... -1.6 % time, profiles/r04_k3_ab_lerp.txt); both maps use the same form,
+// so identical maps still give a loss of exactly 0.  0 restores the two-product form (A/B builds).
+#ifndef SVBRDF_F_AS_LERP
+#define SVBRDF_F_AS_LERP 1
+#endif
+#ifndef SVBRDF_K3_PIPELINE
+#define SVBRDF_K3_PIPELINE 1       // 0: geometry of a render computed in its own pass (no unused geometry after the last render)
+#endif
 #ifndef SVBRDF_K3_MIN_WAVES
 #define SVBRDF_K3_MIN_WAVES 4      // waves/SIMD the register allocator must leave room for (128 VGPRs)
 #endif
@@ -199,7 +222,9 @@ __device__ __forceinline__ Geom geometry(const VConst &K, const float sc[9], flo
     const Recip ih = length_rn(dot3(sx, sy, sz, sx, sy, sz), yh);
     g.hx = div_rn(sx, ih); g.hy = div_rn(sy, ih); g.hz = div_rn(sz, ih);
     // from here on the computation is well conditioned: 1-ULP primitives are enough
-    const float VH = fmaxf(dot3(g.wox, g.woy, g.woz, g.hx, g.hy, g.hz), K.tiny);
+    // (wo.h feeds only the Fresnel factor: no exact dot product needed, see SVBRDF_FMA_VN_LN)
+    const float VH = fmaxf(SVBRDF_FMA_VN_LN ? fma_(g.wox, g.hx, fma_(g.woy, g.hy, g.woz * g.hz))
+                                            : dot3(g.wox, g.woy, g.woz, g.hx, g.hy, g.hz), K.tiny);
     const float t = 1.0f - VH;
     const float t2 = t * t;
     g.p = (t2 * t2) * t;
@@ -265,8 +290,13 @@ __device__ __forceinline__ Dots dots(const VConst &K, const Geom &g, const MapK 
 {
     Dots d;
     d.nh_raw = dot3(m.n[0], m.n[1], m.n[2], g.hx, g.hy, g.hz);
-    d.vn_raw = dot3(g.wox, g.woy, g.woz, m.n[0], m.n[1], m.n[2]);
-    d.ln_raw = dot3(g.wix, g.wiy, g.wiz, m.n[0], m.n[1], m.n[2]);
+    if (SVBRDF_FMA_VN_LN) {
+        d.vn_raw = fma_(g.wox, m.n[0], fma_(g.woy, m.n[1], g.woz * m.n[2]));
+        d.ln_raw = fma_(g.wix, m.n[0], fma_(g.wiy, m.n[1], g.wiz * m.n[2]));
+    } else {
+        d.vn_raw = dot3(g.wox, g.woy, g.woz, m.n[0], m.n[1], m.n[2]);
+        d.ln_raw = dot3(g.wix, g.wiy, g.wiz, m.n[0], m.n[1], m.n[2]);
+    }
     d.NH = fmaxf(d.nh_raw, K.tiny);
     d.VN = fmaxf(d.vn_raw, K.tiny);
     d.LN = fmaxf(d.ln_raw, K.tiny);
@@ -339,15 +369,21 @@ __device__ __forceinline__ void shade(const VConst &K, const Geom &g, const MapK
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         F[k] = fma_(m.oms[k], g.p, m.s[k]);                               // Schlick, renderers.py:29-32
-        const float spec = F[k] * lb[NL == 3 ? k : 0].GD;                   // GD carries the 1/(4 VN LN)
-        f[k] = fma_(1.0f - F[k], m.dpi[k], spec);                         // renderers.py:18-20, 62-65
+        if (SVBRDF_F_AS_LERP) {                                           // f = d/pi + F (GD - d/pi): one instruction fewer
+            f[k] = fma_(F[k], lb[NL == 3 ? k : 0].GD - m.dpi[k], m.dpi[k]);
+        } else {
+            const float spec = F[k] * lb[NL == 3 ? k : 0].GD;               // GD carries the 1/(4 VN LN)
+            f[k] = fma_(1.0f - F[k], m.dpi[k], spec);                     // renderers.py:18-20, 62-65
+        }
         rad[k] = f[k] * (g.E[k] * d.LNp);
     }
 }
 
 // adjoint of shade() with PyTorch's sub-gradient conventions: clamp(min=m) passes the
 // gradient iff x >= m (inclusive); xi() has zero gradient (renderers.py:15-16).
-template <int NL>
+// DEFER_D / DEFER_R: acc.d accumulates g_f (1-F) without the 1/pi and acc.r accumulates gGD KA without dA/dr_hat; the
+// caller applies the two per-pixel constants once after its scene loop (apply_deferred_scales).
+template <int NL, bool DEFER_D = false, bool DEFER_R = false>
 __device__ __forceinline__ void shade_bwd(const VConst &K, const Geom &g, const MapK &m, const Dots &d, const Lobe lb[NL],
                                           const float F[3], const float f[3], const float g_rad[3], Grad &acc)
 {
@@ -362,11 +398,12 @@ __device__ __forceinline__ void shade_bwd(const VConst &K, const Geom &g, const 
         const float gE = g_rad[k] * g.E[k];
         const float g_f = gE * d.LNp;
         g_LNp = k == 0 ? gE * f[k] : fma_(gE, f[k], g_LNp);
-        const float g_F = fma_(g_f, l.GD, -(g_f * m.dpi[k]));             // f = (1-F) d/pi + F GD
+        const float g_F = SVBRDF_F_AS_LERP ? g_f * (l.GD - m.dpi[k])
+                                           : fma_(g_f, l.GD, -(g_f * m.dpi[k]));   // f = (1-F) d/pi + F GD
         acc.s[k] = fma_(g_F, omp, acc.s[k]);
-        acc.d[k] = fma_(g_f * (1.0f - F[k]), inv_pi, acc.d[k]);
+        acc.d[k] = DEFER_D ? fma_(g_f, 1.0f - F[k], acc.d[k]) : fma_(g_f * (1.0f - F[k]), inv_pi, acc.d[k]);
         const float gGD = g_f * F[k];                                     // d loss/d GD
-        acc.r[k] = fma_(gGD * l.KA, m.r4m[k], acc.r[k]);
+        acc.r[k] = DEFER_R ? fma_(gGD, l.KA, acc.r[k]) : fma_(gGD * l.KA, m.r4m[k], acc.r[k]);
         if (NL == 3 || k == 0) W[NL == 3 ? k : 0] = gGD;
         else W[0] += gGD;
     }
@@ -799,7 +836,7 @@ constexpr unsigned long long kLossTicketMask = 0xffffffffULL;   // ws[kLossSlots
 constexpr unsigned long long kLossNonFiniteFlag = 1ULL << 32;   // bit 32 = some workgroup's partial sum was not finite
 
 // one (pixel, scene) of the fused loss: both shadings, log/L1, adjoint of the input shading
-template <int NL, bool WITH_GRAD>
+template <int NL, bool WITH_GRAD, int DEFER = 0>
 __device__ __forceinline__ void loss_pixel_scene(const VConst &K, const Geom &g, const MapK &mi,
                                                  const MapK &mt, float eps, float inv_count, float &lsum, Grad &acc)
 {
@@ -867,7 +904,7 @@ __device__ __forceinline__ void loss_pixel_scene(const VConst &K, const Geom &g,
     if (SVBRDF_ABLATE == 4) {
         acc.n[0] += g_rad[0]; acc.n[1] += g_rad[1]; acc.n[2] += g_rad[2];
     } else if (WITH_GRAD) {
-        shade_bwd<NL>(K, g, mi, di, li, Fi, fi, g_rad, acc);
+        shade_bwd<NL, (DEFER & 1) != 0, (DEFER & 2) != 0>(K, g, mi, di, li, Fi, fi, g_rad, acc);
     }
 }
 
@@ -877,7 +914,7 @@ __device__ __forceinline__ void loss_pixel_scene(const VConst &K, const Geom &g,
 // partials (15 values) and three F/f pairs alive across the loss term and cost the three-lobe loop 19 scratch
 // accesses and ~60 register moves per iteration (510 VALU; 77.8 us at config 2).  Price: the three 1/(render+eps)
 // are three v_rcp here instead of one.
-template <bool WITH_GRAD>
+template <bool WITH_GRAD, int DEFER = 0>
 __device__ __forceinline__ void loss_pixel_scene_by_channel(const VConst &K, const Geom &g, const MapK &mi, const MapK &mt,
                                                             float eps, float inv_count, float &lsum, Grad &acc)
 {
@@ -891,11 +928,11 @@ __device__ __forceinline__ void loss_pixel_scene_by_channel(const VConst &K, con
     for (int k = 0; k < 3; ++k) {
         const Lobe lt = lobe<false>(K, mt.A[k], mt.oA[k], dt);
         const float Ft = fma_(mt.oms[k], g.p, mt.s[k]);
-        const float ft = fma_(1.0f - Ft, mt.dpi[k], Ft * lt.GD);
+        const float ft = SVBRDF_F_AS_LERP ? fma_(Ft, lt.GD - mt.dpi[k], mt.dpi[k]) : fma_(1.0f - Ft, mt.dpi[k], Ft * lt.GD);
         const float rt = ft * (g.E[k] * dt.LNp);
         const Lobe li = lobe<WITH_GRAD>(K, mi.A[k], mi.oA[k], di);
         const float Fi = fma_(mi.oms[k], g.p, mi.s[k]);
-        const float fi = fma_(1.0f - Fi, mi.dpi[k], Fi * li.GD);
+        const float fi = SVBRDF_F_AS_LERP ? fma_(Fi, li.GD - mi.dpi[k], mi.dpi[k]) : fma_(1.0f - Fi, mi.dpi[k], Fi * li.GD);
         const float ri = fi * (g.E[k] * di.LNp);
         const float b = fma_(ri, c, ec), bt = fma_(rt, c, ec);
         const float ib = rcp_(b);
@@ -907,11 +944,11 @@ __device__ __forceinline__ void loss_pixel_scene_by_channel(const VConst &K, con
             const float gE = g_rad * g.E[k];
             const float g_f = gE * di.LNp;
             g_LNp = fma_(gE, fi, g_LNp);
-            const float g_F = fma_(g_f, li.GD, -(g_f * mi.dpi[k]));
+            const float g_F = SVBRDF_F_AS_LERP ? g_f * (li.GD - mi.dpi[k]) : fma_(g_f, li.GD, -(g_f * mi.dpi[k]));
             acc.s[k] = fma_(g_F, omp, acc.s[k]);
-            acc.d[k] = fma_(g_f * (1.0f - Fi), K.inv_pi, acc.d[k]);
+            acc.d[k] = (DEFER & 1) ? fma_(g_f, 1.0f - Fi, acc.d[k]) : fma_(g_f * (1.0f - Fi), K.inv_pi, acc.d[k]);
             const float gGD = g_f * Fi;
-            acc.r[k] = fma_(gGD * li.KA, mi.r4m[k], acc.r[k]);
+            acc.r[k] = (DEFER & 2) ? fma_(gGD, li.KA, acc.r[k]) : fma_(gGD * li.KA, mi.r4m[k], acc.r[k]);
             g_VN = fma_(gGD, li.KV, g_VN);
             g_LN = fma_(gGD, li.KL, g_LN);
             sN = fma_(gGD, li.KN, sN);
@@ -933,14 +970,14 @@ __device__ __forceinline__ void loss_pixel_scene_by_channel(const VConst &K, con
 #ifndef SVBRDF_UNTIED_BY_CHANNEL
 #define SVBRDF_UNTIED_BY_CHANNEL 1
 #endif
-template <int NL, bool WITH_GRAD>
+template <int NL, bool WITH_GRAD, int DEFER = 0>
 __device__ __forceinline__ void loss_pixel_scene_any(const VConst &K, const Geom &g, const MapK &mi, const MapK &mt,
                                                      float eps, float inv_count, float &lsum, Grad &acc)
 {
     if (NL == 3 && SVBRDF_UNTIED_BY_CHANNEL && SVBRDF_ABLATE == 0)
-        loss_pixel_scene_by_channel<WITH_GRAD>(K, g, mi, mt, eps, inv_count, lsum, acc);
+        loss_pixel_scene_by_channel<WITH_GRAD, DEFER>(K, g, mi, mt, eps, inv_count, lsum, acc);
     else
-        loss_pixel_scene<NL, WITH_GRAD>(K, g, mi, mt, eps, inv_count, lsum, acc);
+        loss_pixel_scene<NL, WITH_GRAD, DEFER>(K, g, mi, mt, eps, inv_count, lsum, acc);
 }
 
 // Scene loop of K3, software-pipelined: the geometry of render s+1 (three rsq-headed dependent
@@ -991,7 +1028,7 @@ struct RematTarget {                  // where the target's planes of this pixel
     size_t plane, pix;
 };
 
-template <int NL, bool WITH_GRAD, int G = 1>
+template <int NL, bool WITH_GRAD, int G = 1, int DEFER = 0>
 __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt_in, float x, float y,
                                                  const float *__restrict__ scp, const float *sc_lds, int S,
                                                  float eps, float inv_count, Grad &acc, RematTarget rt = RematTarget{nullptr, 0, 0})
@@ -1038,12 +1075,24 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt_
                 Maps tm;                                                                                           \
                 load_maps_k3(rt.base, rt.plane, rt.pix + opaque, tm);                                              \
                 const MapK mt = prepare<false>(tm);                                                                \
-                loss_pixel_scene_any<NL, WITH_GRAD>(K, G_CUR, mi, mt, eps, inv_count, lsum, acc);                  \
+                loss_pixel_scene_any<NL, WITH_GRAD, DEFER>(K, G_CUR, mi, mt, eps, inv_count, lsum, acc);                  \
             } else {                                                                                               \
-                loss_pixel_scene_any<NL, WITH_GRAD>(K, G_CUR, mi, mt_in, eps, inv_count, lsum, acc);               \
+                loss_pixel_scene_any<NL, WITH_GRAD, DEFER>(K, G_CUR, mi, mt_in, eps, inv_count, lsum, acc);               \
             }                                                                                                      \
         }
-        if (SVBRDF_K3_UNROLL2 && SVBRDF_K3_PEEL_LAST) {
+        if (!SVBRDF_K3_PIPELINE) {
+            // every render in its own pass: scalars of render s+1 prefetched, geometry of render s, shading of render s
+            for (int s = 0; s < S; ++s) {
+                asm volatile("" ::"s"(sc[0]), "s"(sc[8]));
+                float cur[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) cur[i] = sc[i];
+                load_scene(scp + (s + 2 < S ? 2 * ST : (s + 1 < S ? ST : 0)), sc);
+                scp += (s + 1 < S) ? ST : 0;
+                loss_pixel_scene_any<NL, WITH_GRAD, DEFER>(K, ga, mi, mt_in, eps, inv_count, lsum, acc);
+                if (s + 1 < S) ga = geometry(K, cur, x, y);
+            }
+        } else if (SVBRDF_K3_UNROLL2 && SVBRDF_K3_PEEL_LAST) {
             // the last render of the wave has no successor whose geometry could ride along: it is shaded by a copy of
             // the pass without the pipelined half (one copy per parity of S) instead of recomputing a geometry nobody
             // uses (~60 VALU + 3 transcendentals per pixel)
@@ -1054,9 +1103,9 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt_
             }
             if (s + 1 < S) {                                     // S - s == 2
                 SVBRDF_K3_PASS(ga, gb, s)
-                loss_pixel_scene_any<NL, WITH_GRAD>(K, gb, mi, mt_in, eps, inv_count, lsum, acc);
+                loss_pixel_scene_any<NL, WITH_GRAD, DEFER>(K, gb, mi, mt_in, eps, inv_count, lsum, acc);
             } else {                                             // S - s == 1
-                loss_pixel_scene_any<NL, WITH_GRAD>(K, ga, mi, mt_in, eps, inv_count, lsum, acc);
+                loss_pixel_scene_any<NL, WITH_GRAD, DEFER>(K, ga, mi, mt_in, eps, inv_count, lsum, acc);
             }
         } else if (SVBRDF_K3_UNROLL2) {
             for (int s = 0;;) {
@@ -1079,10 +1128,17 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt_
             const Geom g = g_next;
             load_scene(sc_lds + (s + 1 < S ? s + 1 : s) * 9, sc);
             g_next = geometry(K, sc, x, y);
-            loss_pixel_scene_any<NL, WITH_GRAD>(K, g, mi, mt_in, eps, inv_count, lsum, acc);
+            loss_pixel_scene_any<NL, WITH_GRAD, DEFER>(K, g, mi, mt_in, eps, inv_count, lsum, acc);
         }
     }
     lsum *= 0.693147180559945309417f;       // the scene loop sums |log2|: natural log once per pixel
+    if (WITH_GRAD && DEFER) {               // the per-pixel constants shade_bwd left out (see its DEFER_D / DEFER_R)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (DEFER & 1) acc.d[k] *= K.inv_pi;
+            if (DEFER & 2) acc.r[k] *= mi.r4m[k];
+        }
+    }
 #if SVBRDF_TIMING
     if (WITH_GRAD) {        // timing build: the normal-gradient planes carry loop cycles / 100 MHz ticks / start stamp
         acc.n[0] = (float)(clock64() - tm0);
@@ -1324,6 +1380,9 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         if (G > 1 && WITH_L1) pin_maps(tg[0]);
         zero_grad(acc);
         float l1sum = 0.0f;
+        // deferred per-pixel constants of the adjoint (shade_bwd): 1/pi of the diffuse gradient always (an L1 start value
+        // is multiplied by pi here), dA/dr_hat of the roughness gradient only where acc.r starts from zero (it can be 0)
+        constexpr int kDefer = (SVBRDF_K3_DEFER_SCALES && WITH_GRAD && G == 1) ? (WITH_L1 ? 1 : 3) : 0;
         if (WITH_L1 && (G == 1 || grp == 0)) {
             // losses.py:7-19.  Same economy of transcendentals as in loss_pixel_scene: the six 1/(x + eps)
             // of the log terms' derivatives come from ONE v_rcp of their product (all six lie in
@@ -1364,6 +1423,7 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
                     acc.n[k] = signed_scale(dn, l1.grad_scale);
                     acc.r[k] = signed_scale(dr, l1.grad_scale);
                     acc.d[k] = signed_scale(dd, l1.grad_scale) * ia[k];
+                    if (kDefer & 1) acc.d[k] *= kPi;
                     acc.s[k] = signed_scale(ds, l1.grad_scale) * ia[3 + k];
                 }
             }
@@ -1401,10 +1461,10 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         const float *__restrict__ scp = scenes + ((size_t)b * S + grp) * 9;
         if (G == 1 || S_own > 0) {
             if (__all(tied))     // wave-uniform: every lane's input AND target roughness channels are tied
-                lsum = loss_scene_loop<1, WITH_GRAD, G>(mi, mt, x[0], y, scp, sc_lds, S_own, eps, inv_count, acc,
-                                                        RematTarget{target + (size_t)b * 12 * plane, plane, pix});
+                lsum = loss_scene_loop<1, WITH_GRAD, G, kDefer>(mi, mt, x[0], y, scp, sc_lds, S_own, eps, inv_count, acc,
+                                                                RematTarget{target + (size_t)b * 12 * plane, plane, pix});
             else
-                lsum = loss_scene_loop<3, WITH_GRAD, G>(mi, mt, x[0], y, scp, sc_lds, S_own, eps, inv_count, acc);
+                lsum = loss_scene_loop<3, WITH_GRAD, G, kDefer>(mi, mt, x[0], y, scp, sc_lds, S_own, eps, inv_count, acc);
         }
         if (WITH_L1) lsum = fma_(l1sum, l1.sum_scale, lsum);
 #if SVBRDF_TIMING

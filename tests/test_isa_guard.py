@@ -11,7 +11,7 @@ kernel k_rendering_loss_inl<GRAD=1,L1=0,HEAD=0> (and, more loosely, the MixedLos
   * three-lobe (untied) scene loop: VALU and transcendental count, no scratch traffic
   * numerics contract: the products of the exact dot products on the coords -> NH path are never contracted into
     FMAs: every dot3 must appear as 3 v_mul + 2 v_add; checked on the stand-alone `svbrdf_isa_probe_dot3` kernel
-    and by counting the plain multiplies/adds of the loop against the FMA count.
+    (n.wo, n.wi and wo.h, which do not feed NH, are explicit FMAs since round 4: SVBRDF_FMA_VN_LN).
 """
 import os
 import re
@@ -30,11 +30,11 @@ HEADLINE = "k_rendering_loss_inlILb1ELb0ELb0"
 # budgets: measured values of the shipped build + a small margin (tools/isa_stats.py prints the current ones).
 # The scene loops hold TWO renders per trip (geometry ping-pong), so the counts are per two renders.
 RENDERS_PER_TRIP = 2
-TIED_LOOP_VALU_MAX = 660             # headline 646 = 323 per render (round 1: 336; round 2: 320, +3 since the L1 sign of an exact-zero log is 0); device-table MixedLoss 656
+TIED_LOOP_VALU_MAX = 618             # headline 602 = 301 per render (round 1: 336; round 2: 320; round 3: 323; round 4: n.wo / n.wi / wo.h as FMAs and the per-pixel gradient constants after the loop, f as d/pi + F (GD - d/pi)); device-table MixedLoss 610
 TIED_LOOP_TRANS = 26                 # 13 per render
-UNTIED_LOOP_VALU_MAX = 880           # RenderingLoss kernel: 864 (three lobes, channel by channel)
+UNTIED_LOOP_VALU_MAX = 842           # RenderingLoss kernel: 826 (three lobes, channel by channel; round 3: 870)
 UNTIED_LOOP_TRANS = 54               # 27 per render
-UNTIED_EXTRA_VALU_MAX = {"mixed": 900, "head": 715}     # MixedLoss 884; head-fused 704 (input tied by construction)
+UNTIED_EXTRA_VALU_MAX = {"mixed": 865, "head": 688}     # MixedLoss 848; head-fused 672 (input tied by construction)
 UNTIED_EXTRA_TRANS = {"mixed": 54, "head": 42}
 UNTIED_EXTRA_SCRATCH_MAX = {"mixed": 16, "head": 0}       # MixedLoss three-lobe loop: 13 spill accesses per trip
 TIED_EXTRA_SCRATCH_MAX = {"mixed": 6, "head": 0}        # device-table MixedLoss kernel: 5 spill accesses per trip

@@ -8,6 +8,9 @@
 #   peel     last render of a wave without the unused successor geometry
 #   plain/nt/ntwt  cache policy of the gradient stores (shipped: sc0 sc1)
 #   late     pixel coordinates loaded after the plane loads (round 3's order)
+#   dot3 / nodef / nolerp / alg0   the shipped build WITHOUT one / all of round 4's instruction-count reductions:
+#            n.wo, n.wi, wo.h as FMAs; 1/pi and 4r^3 of the gradient once per pixel; f as d/pi + F (GD - d/pi)
+#   nopipe   geometry of a render in its own pass (no unused geometry after the last render, no interleave)
 #   prio1/2  s_setprio by remaining renders: last resident round only / every wave
 #   stag32   first round's plane loads issued in four layers, s_sleep 32 apart
 # Usage on the GPU box: bash tools/round4_ab.sh > gpurun_out/r04_k3_ab.txt
@@ -26,7 +29,7 @@ for round in 1 2; do
     one "$tag" $B/libsvbrdf_r3.so ${envs//,/ }
     one "$tag" $B/libsvbrdf_r4.so ${envs//,/ }
     for g in 2 3 4; do one "$tag" $B/libsvbrdf_r4split.so SVBRDF_K3_SPLIT=$g ${envs//,/ } | sed "s/r4split /split=$g /"; done
-    for v in t64 t128 peel plain nt ntwt late p1 p2 s32; do one "$tag" $B/libsvbrdf_r4$v.so ${envs//,/ }; done
+    for v in dot3 nodef nolerp alg0 nopipe t64 t128 peel plain nt ntwt late p1 p2 s32; do one "$tag" $B/libsvbrdf_r4$v.so ${envs//,/ }; done
   done
   MODES=6 one "floor" $B/libsvbrdf_r4.so | sed 's/$/   (a kernel that exits at once, launched back to back)/'
 done

@@ -17,6 +17,11 @@ bash tools/build_variant.sh r4plain -DSVBRDF_K3_STORE_AUX=0            # gradien
 bash tools/build_variant.sh r4nt -DSVBRDF_K3_STORE_AUX=2
 bash tools/build_variant.sh r4ntwt -DSVBRDF_K3_STORE_AUX=19
 bash tools/build_variant.sh r4late -DSVBRDF_K3_EARLY_COORDS=0          # coordinates loaded after the planes (round 3)
+bash tools/build_variant.sh r4dot3 -DSVBRDF_FMA_VN_LN=0                # n.wo, n.wi, wo.h as three rounded products + two adds (round 3)
+bash tools/build_variant.sh r4nodef -DSVBRDF_K3_DEFER_SCALES=0         # 1/pi and 4r^3 of the gradient per render and channel (round 3)
+bash tools/build_variant.sh r4nolerp -DSVBRDF_F_AS_LERP=0              # f = (1-F) d/pi + F GD as two products (round 3)
+bash tools/build_variant.sh r4alg0 -DSVBRDF_FMA_VN_LN=0 -DSVBRDF_K3_DEFER_SCALES=0 -DSVBRDF_F_AS_LERP=0   # none of the three
+bash tools/build_variant.sh r4nopipe -DSVBRDF_K3_PIPELINE=0            # geometry of a render in its own pass
 bash tools/build_variant.sh r4p1 -DSVBRDF_K3_TAIL_PRIO=1
 bash tools/build_variant.sh r4p2 -DSVBRDF_K3_TAIL_PRIO=2
 bash tools/build_variant.sh r4s32 -DSVBRDF_K3_STAGGER=32
