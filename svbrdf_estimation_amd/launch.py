@@ -179,6 +179,7 @@ def gpu_render_minors(sysfs="/sys", environ=None):
             continue
         if int(props.get("simd_count", "0")) > 0:
             minors.append(int(props.get("drm_render_minor", "-1")))
+            _PCI_OF_MINOR[minors[-1]] = (int(props.get("domain", "0")), int(props.get("location_id", "0")))
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES" if "HIP_VISIBLE_DEVICES" in environ else "CUDA_VISIBLE_DEVICES"):
         idx = _visible_indices(environ.get(var), len(minors))
         if idx is None:
@@ -187,12 +188,25 @@ def gpu_render_minors(sysfs="/sys", environ=None):
     return minors
 
 
+_PCI_OF_MINOR = {}      # render minor -> (PCI domain, KFD location_id = bus << 8 | devfn), filled by gpu_render_minors
+
+
 def _numa_node_of_minor(minor, sysfs):
-    try:
-        node = int(_read(os.path.join(sysfs, "class", "drm", "renderD%d" % minor, "device", "numa_node")).strip())
-    except (OSError, ValueError):
-        return None
-    return node if node >= 0 else None
+    """NUMA node of a GPU: from its DRM render node, or -- for the render nodes of compute partitions, which are platform
+    devices without one -- from the PCI function the KFD topology names (domain, location_id)."""
+    paths = [os.path.join(sysfs, "class", "drm", "renderD%d" % minor, "device", "numa_node")]
+    if minor in _PCI_OF_MINOR:
+        domain, loc = _PCI_OF_MINOR[minor]
+        paths.append(os.path.join(sysfs, "bus", "pci", "devices",
+                                  "%04x:%02x:%02x.%d" % (domain, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7), "numa_node"))
+    for path in paths:
+        try:
+            node = int(_read(path).strip())
+        except (OSError, ValueError):
+            continue
+        if node >= 0:
+            return node
+    return None
 
 
 def _cores(cpus, sysfs):

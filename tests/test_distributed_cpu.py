@@ -284,6 +284,16 @@ def test_rank_cpu_placement_follows_the_gpu_numa_node(tmp_path):
         u = launch.rank_cpu_placement(0, world, sysfs=root, environ=env, allowed=allowed)
         assert u["numa_node"] is None and u["cpus"] == allowed and u["source"].startswith("unbound")
     assert launch.rank_cpu_placement(0, 1, sysfs=str(tmp_path / "nothing"), environ={}, allowed=allowed)["numa_node"] is None
+    # a compute-partition render node has no numa_node of its own: the PCI function the KFD topology names is asked
+    root3 = str(tmp_path / "sys3")
+    _fake_sysfs(root3, [1], nodes)
+    os.remove(os.path.join(root3, "class/drm/renderD128/device/numa_node"))
+    with open(os.path.join(root3, "class/kfd/kfd/topology/nodes/2/properties"), "a") as f:
+        f.write("domain 0\nlocation_id 41984\n")                              # bus 0xa4, device 0, function 0
+    os.makedirs(os.path.join(root3, "bus/pci/devices/0000:a4:00.0"))
+    with open(os.path.join(root3, "bus/pci/devices/0000:a4:00.0/numa_node"), "w") as f:
+        f.write("1\n")
+    assert launch.rank_cpu_placement(0, 1, sysfs=root3, environ={}, allowed=allowed)["numa_node"] == 1
 
 
 def test_bind_rank_pins_the_process_and_reports_a_cpulist(tmp_path):

@@ -5,7 +5,7 @@
 # Afterwards, here: python tools/summarize_profiles.py r04; copy the r04_* text files from gpurun_out/ to profiles/.
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q -s 2>&1 | grep -v "^\[tolerance\]" | tail -25 > gpurun_out/r04_gputest.txt
+python -m pytest tests -m gpu -x -q -s 2>&1 | grep -E "^\[datapath\]|^rank placement|over RCCL|two ranks on one device|DDP \(2 ranks\)|config 4 end to end|ledger:|passed|failed|Error" > gpurun_out/r04_gputest.txt
 tail -4 gpurun_out/r04_gputest.txt
 cp gpurun_out/tolerance_uses.txt gpurun_out/r04_tolerance_uses.txt 2>/dev/null
 if [ -z "$SKIP_AB" ]; then
