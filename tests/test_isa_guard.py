@@ -112,6 +112,19 @@ def test_plane_loads_are_issued_back_to_back(adjoint_asm, adjoint_extra_asm):
             if early:
                 rsq = next(i for i, (_, _, mn, _) in enumerate(ins) if mn and mn.startswith("v_rsq_f32") and i > loads[-1])
                 assert any(m == "s_waitcnt" and o.strip() == "vmcnt(0)" for _, _, m, o in ins[loads[-1]:rsq] if m), k
+                # ... and nothing may touch the two destination registers before that wait: the compiler believes they
+                # hold their values from the asm statement on, so a copy or a spill in between would capture garbage
+                wait = next(i for i in range(loads[-1], rsq) if ins[i][2] == "s_waitcnt" and ins[i][3].strip() == "vmcnt(0)")
+                dests = [ins[i][3].split(",")[0].strip() for i in early]
+                assert all(re.fullmatch(r"v\d+", d) for d in dests), dests
+                for i in range(early[0] + 1, wait):
+                    mn, ops = ins[i][2], ins[i][3] or ""
+                    if not mn or i in early:
+                        continue
+                    regs = set(re.findall(r"\bv(\d+)\b", ops))
+                    for lo, hi in re.findall(r"v\[(\d+):(\d+)\]", ops):
+                        regs.update(str(r) for r in range(int(lo), int(hi) + 1))
+                    assert not ({d[1:] for d in dests} & regs), "%s: %s %s touches an early coordinate register before the wait" % (k, mn, ops)
 
 
 def test_scene_loops_instruction_budget(adjoint_asm):

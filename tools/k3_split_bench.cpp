@@ -80,11 +80,18 @@ int main()
     }
     CA(svbrdf_make_xrow(xr.data(), W));
     constexpr int NS = 4;
+    // K3_ROTATE=N: N distinct (input, target, gradient) sets visited round-robin by the launches -- 6 x 75 MB exceeds the
+    // 256 MiB Infinity Cache, so the maps come from HBM as in bench.py; the default single set stays cache-resident
+    const int rotate = std::getenv("K3_ROTATE") ? std::atoi(std::getenv("K3_ROTATE")) : 1;
+    static int rot_k = 0;
     float *d_in, *d_tg, *d_xr, *d_grad, *d_loss; unsigned long long *d_ws;
     const size_t wsb = svbrdf_rendering_loss_workspace_bytes(B, S, H, W);
-    CK(hipMalloc(&d_in, n * 4)); CK(hipMalloc(&d_tg, n * 4)); CK(hipMalloc(&d_grad, n * 4));
+    CK(hipMalloc(&d_in, n * 4 * rotate)); CK(hipMalloc(&d_tg, n * 4 * rotate)); CK(hipMalloc(&d_grad, n * 4 * rotate));
     CK(hipMalloc(&d_xr, W * 4)); CK(hipMalloc(&d_loss, 4 * NS)); CK(hipMalloc(&d_ws, wsb * NS)); CK(hipMemset(d_ws, 0, wsb * NS));
-    CK(hipMemcpy(d_in, in.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_tg, tg.data(), n * 4, hipMemcpyHostToDevice));
+    for (int r = 0; r < rotate; ++r) {
+        CK(hipMemcpy(d_in + (size_t)r * n, in.data(), n * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_tg + (size_t)r * n, tg.data(), n * 4, hipMemcpyHostToDevice));
+    }
     CK(hipMemcpy(d_xr, xr.data(), W * 4, hipMemcpyHostToDevice));
     float *d_one; const float one = 1.0f;
     CK(hipMalloc(&d_one, 4)); CK(hipMemcpy(d_one, &one, 4, hipMemcpyHostToDevice));
@@ -97,9 +104,10 @@ int main()
     // part p of `parts` on stream s: items [p*B/parts, (p+1)*B/parts)
     auto launch = [&](int p, int parts, int s) -> int {
         const int b0 = p * B / parts, nb = (p + 1) * B / parts - b0;
-        return svbrdf_mixed_loss_fwd_bwd_host_scenes(d_in + (size_t)b0 * cin * plane, d_tg + (size_t)b0 * 12 * plane,
+        const size_t ro = (size_t)(rot_k++ % rotate) * n;
+        return svbrdf_mixed_loss_fwd_bwd_host_scenes(d_in + ro + (size_t)b0 * cin * plane, d_tg + ro + (size_t)b0 * 12 * plane,
                                                      sc.data() + (size_t)b0 * S * 9, d_xr, 0.1f, l1w, 0.01f, d_loss + s,
-                                                     d_grad + (size_t)b0 * cin * plane, (char *)d_ws + wsb * s, wsb, nb, S, H, W, st[s]);
+                                                     d_grad + ro + (size_t)b0 * cin * plane, (char *)d_ws + wsb * s, wsb, nb, S, H, W, st[s]);
     };
     struct Mode { const char *name; int parts; bool join; bool alternate; };
     const Mode modes[] = {
