@@ -778,7 +778,8 @@ def main():
                                         if B * S <= _native.host_scenes_max_rows() else "pinned-ring upload",
                          "kernel_limited_patches_per_s": B / (share_ms * 1e-3),
                          "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
-                         "kernel_ms_note": "event pairs around a SAMPLE of the launches (every 32nd of the timed region; for a region "
+                         "kernel_ms_note": "a sampled event PAIR spans dispatch gap (~3 us) + kernel + event bubble: exceeds time_per_launch_ms by design.  "
+                                           "Pairs bracket a SAMPLE of the launches (every 32nd of the timed region; for a region "
                                            "shorter than 256 steps: every 16th of an untimed 512-step leg right after it).  A pair on a "
                                            "back-to-back stream spans the launch AND the ~3 us dispatch gap in front of it plus its own "
                                            "end-of-pipe bubble, so it reads longer than time_per_launch_ms (and than ms_per_step); "

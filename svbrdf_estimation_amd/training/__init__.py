@@ -18,6 +18,8 @@ def use_in_tree_miopen_cache():
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_cache")
     if not os.path.isdir(os.path.join(here, "cache")):
         return None
+    if os.environ.get("MIOPEN_CUSTOM_CACHE_DIR") == os.path.join(here, "cache"):
+        return here                     # a parent process (the test suite) already pointed MIOpen at the in-tree cache
     if "MIOPEN_CUSTOM_CACHE_DIR" in os.environ or "MIOPEN_USER_DB_PATH" in os.environ:
         return None
     os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(here, "cache")

@@ -130,6 +130,18 @@ def test_bench_gpus_n_spawns_n_ranks_without_a_launcher():
     assert len(pr["cpus"]) == 2 and all(isinstance(c, str) and c for c in pr["cpus"]) and len(pr["cpu_binding"]) == 2
 
 
+def test_bench_gpus_8_plumbing_as_the_scaling_run_starts_it():
+    """the driver's scaling run ends at `bench.py --gpus 8`: eight self-spawned ranks, one rendezvous, one JSON line with
+    eight per-rank entries (GPU work left out: --plumbing-only)"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo",
+                        "--plumbing-only"], env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["ranks_seen"] == 8, r.stdout
+    assert len(lines[0]["per_rank"]["cpus"]) == 8 and lines[0]["elapsed_max_over_ranks_s"] >= 0.08    # rank 7 sleeps 80 ms
+
+
 def test_bench_refuses_a_world_that_is_not_gpus():
     """a launcher environment whose WORLD_SIZE contradicts --gpus must be an error, not a silent 1-rank run"""
     import subprocess

@@ -88,6 +88,24 @@ def test_bench_two_self_spawned_ranks_share_the_device():
         json.dump(line, f, indent=1)
 
 
+def test_bench_eight_self_spawned_ranks_as_the_scaling_run_starts_it():
+    """`python bench.py --gpus 8 --steps 20 --warmup 5` as ONE plain process -- the last command of the driver's scaling
+    run -- on the one GPU a box has (gloo, every rank on cuda:0): eight fresh rank processes, eight scene streams, eight
+    CPU slices of the GPU's socket (disjoint where the topology is readable), MAX over ranks, one JSON line."""
+    line, _ = _run("bench.py", "--gpus", 8, "--backend", "gloo", "--share-device", "--steps", 20, "--warmup", 5,
+                   "--settle-ms", 20, "--no-cpu-baseline", "--no-secondary", timeout=1500)
+    assert line["launch"] == "self-spawned" and line["ranks_seen"] == 8 and line["n_gpus"] == 8
+    pr = line["per_rank"]
+    assert pr["scene_seed"] == list(range(313, 321)) and len(set(pr["last_loss"])) == 8
+    assert len(pr["ms_per_step"]) == 8 and abs(line["per_gpu_value"] * 8 - line["value"]) <= 1e-9 * line["value"]
+    assert line["ms_per_step"] * line["steps"] * 1e-3 >= max(pr["elapsed_s"]) * (1 - 1e-9)
+    from svbrdf_estimation_amd import launch
+    cpus = [set(launch.parse_cpulist(c)) for c in pr["cpus"]]
+    if pr["numa_node"][0] is not None:
+        assert len(set(pr["numa_node"])) == 1 and all(a.isdisjoint(b) for i, a in enumerate(cpus) for b in cpus[i + 1:]), pr["cpus"]
+    print("bench.py, eight ranks on one device: %.0f patches/s aggregate; slices %s" % (line["value"], pr["cpus"]))
+
+
 def test_train_rccl_ddp_world_of_one():
     """train.py's N > 1 branches over RCCL at world size 1: process group with device_id, DistributedDataParallel
     around the U-Net (bucketed all-reduce of its 320 MB of gradients through RCCL), fused MixedLoss, barriers, the
