@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void loss_pixel_scene_any(const VConst &K, const Geom
 #define SVBRDF_K3_TAIL_PRIO 0
 #endif
 #ifndef SVBRDF_K3_STAGGER
-#define SVBRDF_K3_STAGGER 0
+#define SVBRDF_K3_STAGGER 48        // s_sleep units (64 cycles) between the load layers of a launch's first round; 0 = off
 #endif
 #ifndef SVBRDF_K3_EARLY_COORDS
 #define SVBRDF_K3_EARLY_COORDS 1    // pixel coordinates loaded in front of the plane loads (rendering_loss_body)
@@ -1324,13 +1324,20 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
     const long long t_entry = wall_clock64();
 #endif
 #if SVBRDF_K3_STAGGER
-    {   // experiment: the first resident round issues its plane loads in four layers (workgroup >> 8 = which of a CU's
-        // four workgroup slots, if placement is round-robin), SVBRDF_K3_STAGGER x 64 cycles apart
-        const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
-        const unsigned layer = bid >> 8;
+    if (WITH_GRAD && G == 1 && EARLY_COORDS && S >= 6) {     // (by-value-table kernels only, like the early coordinate loads)
+        // The first resident round of a launch -- 1024 workgroups, 4096 waves -- issues 25 MB of plane loads within 0.4 us,
+        // and when the maps come from HBM every one of those waves gets its last plane at about the same time, 4-5 us
+        // later: nobody computes until then.  Issued in four layers (workgroup >> 8 = which of a CU's four workgroup
+        // slots it takes, the dispatcher filling the CUs breadth-first), SVBRDF_K3_STAGGER x 64 cycles apart, the first
+        // layer's loads meet an idle memory system and its waves are in their scene loops while the later layers' data
+        // arrives.  Same-box A/B (profiles/r04_k3_ab_stagger_hbm.txt): -1.4 ... -2.6 % per launch with the maps from
+        // HBM, neutral with cache-resident maps; 48 and 64 units best.  Only for launches whose waves live long enough
+        // (>= 6 renders per pixel: the loss configurations of the reference have 9 and 32).  A different placement
+        // order would make this a harmless delay, not an error.
+        const unsigned layer = (blockIdx.y * gridDim.x + blockIdx.x) >> 8;
         if (layer == 1) __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER);
-        else if (layer == 2) __builtin_amdgcn_s_sleep(2 * SVBRDF_K3_STAGGER);
-        else if (layer == 3) __builtin_amdgcn_s_sleep(3 * SVBRDF_K3_STAGGER);
+        else if (layer == 2) { __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); }
+        else if (layer == 3) { __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); }
     }
 #endif
     if (!WITH_GRAD) {    // forward-only kernels stage the scene table of batch item b in LDS (see loss_scene_loop)

@@ -12,7 +12,9 @@
 #            n.wo, n.wi, wo.h as FMAs; 1/pi and 4r^3 of the gradient once per pixel; f as d/pi + F (GD - d/pi)
 #   nopipe   geometry of a render in its own pass (no unused geometry after the last render, no interleave)
 #   prio1/2  s_setprio by remaining renders: last resident round only / every wave
-#   stag32   first round's plane loads issued in four layers, s_sleep 32 apart
+#   nostag   first round's plane loads all at once (shipped: four layers, 48 x 64 cycles apart; matters with maps from HBM)
+# Part 2 repeats the comparison for the changes that depend on it with the maps coming from HBM (K3_ROTATE=6: six sets of
+# maps, 453 MB, beyond the 256 MiB Infinity Cache -- what bench.py measures); part 1 keeps ONE set cache-resident.
 # Usage on the GPU box: bash tools/round4_ab.sh > gpurun_out/r04_k3_ab.txt
 cd "$(dirname "$0")/.."
 B=tools/_build
@@ -29,7 +31,15 @@ for round in 1 2; do
     one "$tag" $B/libsvbrdf_r3.so ${envs//,/ }
     one "$tag" $B/libsvbrdf_r4.so ${envs//,/ }
     for g in 2 3 4; do one "$tag" $B/libsvbrdf_r4split.so SVBRDF_K3_SPLIT=$g ${envs//,/ } | sed "s/r4split /split=$g /"; done
-    for v in dot3 nodef nolerp alg0 nopipe t64 t128 peel plain nt ntwt late p1 p2 s32; do one "$tag" $B/libsvbrdf_r4$v.so ${envs//,/ }; done
+    for v in dot3 nodef nolerp alg0 nopipe t64 t128 peel plain nt ntwt late nostag p1 p2; do one "$tag" $B/libsvbrdf_r4$v.so ${envs//,/ }; done
   done
   MODES=6 one "floor" $B/libsvbrdf_r4.so | sed 's/$/   (a kernel that exits at once, launched back to back)/'
+done
+echo "== part 2: maps from HBM (K3_ROTATE=6), median-friendly: three rounds"
+for round in 1 2 3; do
+  echo "== hbm round $round"
+  for cfg in "tied:" "untied:K3_UNTIED=1" "mixed:K3_L1=0.1" "tied-B16:K3_B=16"; do
+    tag=${cfg%%:*}; envs=${cfg#*:}
+    for v in r3 r4 r4nostag r4plain r4late r4alg0; do one "$tag" $B/libsvbrdf_$v.so K3_ROTATE=6 ${envs//,/ }; done
+  done
 done

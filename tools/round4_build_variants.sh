@@ -24,6 +24,6 @@ bash tools/build_variant.sh r4alg0 -DSVBRDF_FMA_VN_LN=0 -DSVBRDF_K3_DEFER_SCALES
 bash tools/build_variant.sh r4nopipe -DSVBRDF_K3_PIPELINE=0            # geometry of a render in its own pass
 bash tools/build_variant.sh r4p1 -DSVBRDF_K3_TAIL_PRIO=1
 bash tools/build_variant.sh r4p2 -DSVBRDF_K3_TAIL_PRIO=2
-bash tools/build_variant.sh r4s32 -DSVBRDF_K3_STAGGER=32
+bash tools/build_variant.sh r4nostag -DSVBRDF_K3_STAGGER=0              # first round's plane loads all at once (round 3)
 bash tools/build_variant.sh r4tim -DSVBRDF_TIMING=1 -DSVBRDF_K3_SPLIT_VARIANTS=1
 hipcc -O2 --offload-arch=gfx950 -Iinclude tools/k3_split_bench.cpp -o tools/_build/k3_split_bench -ldl
