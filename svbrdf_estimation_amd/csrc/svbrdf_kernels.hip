@@ -521,6 +521,9 @@ __device__ __forceinline__ void store_grads(float *__restrict__ base, size_t pla
 // with two launches in flight; nt alone gains 1.1).  A/B builds: 0 = plain, 2 = nt, 17 = sc0 sc1, 19 = all three.
 #define SVBRDF_K3_STORE_AUX 17
 #endif
+#ifndef SVBRDF_K3_LOAD_AUX
+#define SVBRDF_K3_LOAD_AUX 0        // cache policy of K3's plane loads (A/B builds: 2 = nt)
+#endif
 struct PlaneBuf {
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned lane_bytes;        // pixel index * 4
@@ -537,7 +540,7 @@ __device__ __forceinline__ PlaneBuf plane_buf(const float *item_base, int planes
 }
 __device__ __forceinline__ float plane_load(const PlaneBuf &p, int k)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(p.rsrc, p.lane_bytes, k * p.plane_bytes, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(p.rsrc, p.lane_bytes, k * p.plane_bytes, SVBRDF_K3_LOAD_AUX));
 }
 __device__ __forceinline__ void plane_store(const PlaneBuf &p, int k, float v)
 {
@@ -1004,7 +1007,10 @@ __device__ __forceinline__ void loss_pixel_scene_any(const VConst &K, const Geom
 #define SVBRDF_K3_TAIL_PRIO 0
 #endif
 #ifndef SVBRDF_K3_STAGGER
-#define SVBRDF_K3_STAGGER 48        // s_sleep units (64 cycles) between the load layers of a launch's first round; 0 = off
+#define SVBRDF_K3_STAGGER 64        // s_sleep units (64 cycles) between the load layers of a launch's first round; 0 = off
+#endif
+#ifndef SVBRDF_K3_STAGGER_LAYERS
+#define SVBRDF_K3_STAGGER_LAYERS 4
 #endif
 #ifndef SVBRDF_K3_EARLY_COORDS
 #define SVBRDF_K3_EARLY_COORDS 1    // pixel coordinates loaded in front of the plane loads (rendering_loss_body)
@@ -1330,14 +1336,25 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         // later: nobody computes until then.  Issued in four layers (workgroup >> 8 = which of a CU's four workgroup
         // slots it takes, the dispatcher filling the CUs breadth-first), SVBRDF_K3_STAGGER x 64 cycles apart, the first
         // layer's loads meet an idle memory system and its waves are in their scene loops while the later layers' data
-        // arrives.  Same-box A/B (profiles/r04_k3_ab_stagger_hbm.txt): -1.4 ... -2.6 % per launch with the maps from
-        // HBM, neutral with cache-resident maps; 48 and 64 units best.  Only for launches whose waves live long enough
-        // (>= 6 renders per pixel: the loss configurations of the reference have 9 and 32).  A different placement
-        // order would make this a harmless delay, not an error.
+        // arrives -- the stagger that age arbitration produces anyway, from the start.  Same-box A/B, medians of three
+        // (profiles/r04_k3_ab_stagger_hbm.txt, r04_k3_ab_stagger_long.txt): with the maps from HBM -3 ... -4 % per launch
+        // for the rendering loss, -1 % for the mixed loss and batch 16; neutral with cache-resident maps; +1 ... +2 % with
+        // two launches in flight.  64 units best (48: half the gain; 80 and more cost one-round launches and the L1
+        // variants; eight or sixteen finer layers: no better, r04_k3_ab_stagger_layers.txt).  Only for launches whose
+        // waves live long enough (>= 6 renders per pixel: the reference's loss has 9, config 5 has 32).  A different
+        // placement order would make this a harmless delay, not an error.
+#if SVBRDF_K3_STAGGER_LAYERS == 4
         const unsigned layer = (blockIdx.y * gridDim.x + blockIdx.x) >> 8;
         if (layer == 1) __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER);
         else if (layer == 2) { __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); }
         else if (layer == 3) { __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); }
+#else   // experiment: finer layers (8 or 16 per resident round), the delay applied layer times
+        const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
+        if (bid < 1024u) {
+            const unsigned layer = bid / (1024u / SVBRDF_K3_STAGGER_LAYERS);
+            for (unsigned i = 0; i < layer; ++i) __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER);
+        }
+#endif
     }
 #endif
     if (!WITH_GRAD) {    // forward-only kernels stage the scene table of batch item b in LDS (see loss_scene_loop)
