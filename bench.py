@@ -57,7 +57,7 @@ def parse_args():
                     help="untimed device settle phase before the W warm-up steps: the same step function is run for "
                          "this long so that clocks (DVFS) and caches are in their steady state even when W is small; "
                          "reported in the JSON line")
-    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+    ap.add_argument("--backend", default=None, choices=("nccl", "gloo"),
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only for plumbing tests of the "
                          "multi-rank control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-device", action="store_true",
@@ -400,6 +400,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.backend is None:        # RCCL (nccl) unless every rank shares cuda:0, which RCCL refuses
+        args.backend = "gloo" if (args.share_device and world > 1) else "nccl"
+    elif args.backend == "nccl" and args.share_device and world > 1:
+        raise SystemExit("--share-device puts every rank on cuda:0, which RCCL does not support: use --backend gloo")
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (or let bench.py spawn them: run it "
                          "without a rank environment)" % (args.gpus, world))
