@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SVBRDF_ABI_VERSION 4
+#define SVBRDF_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define SVBRDF_API __attribute__((visibility("default")))
@@ -204,6 +204,18 @@ SVBRDF_API int svbrdf_mix_materials(const float *svbrdf0, const float *svbrdf1, 
  * cycles / ticks * 0.1 = the shader clock in GHz while whatever else is running runs (bench.py launches it on a
  * stream of its own beside the fused loss: the clock the chip holds under that kernel). */
 SVBRDF_API int svbrdf_debug_clock_probe(unsigned long long *out_dev, unsigned long long ticks_100mhz, void *stream);
+
+/* float64 maps (ABI version 5).  LocalRenderer.render is dtype-agnostic in the reference (renderers.py:67-104); with double
+ * maps it computes in MIXED precision: pixel grid (torch.linspace, :73), camera / light positions and light colour
+ * (torch.Tensor(...), :79,:91,:98) are float32, so wo, wi, h, (1-VH)^5 and colour*falloff are the float32 values of the
+ * float32 path, and everything that touches the maps is promoted to double.  These two entry points do exactly that:
+ *   maps / grad_maps [B,12,H,W] double, scenes [B,S,9] float32 DEVICE, xrow [W] float32, out / grad_out [B,S,3,H,W] double.
+ * Shading op by op in the reference's order (the slow path of gradient checks and notebooks, not of training); the losses
+ * for double maps are composed from these through autograd on the host side.  Same error convention as above. */
+SVBRDF_API int svbrdf_render_fwd_f64(const double *maps, const float *scenes, const float *xrow, double *out,
+                                     int B, int S, int H, int W, void *stream);
+SVBRDF_API int svbrdf_render_bwd_f64(const double *maps, const float *scenes, const float *xrow, const double *grad_out,
+                                     double *grad_maps, int B, int S, int H, int W, void *stream);
 
 #ifdef __cplusplus
 }

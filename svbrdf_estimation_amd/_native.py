@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SVBRDF_HIP_LIB: load another build of the same ABI (ablation/experiment builds of tools/); default in-tree
 _SO = os.environ.get("SVBRDF_HIP_LIB") or os.path.join(_HERE, "lib", "libsvbrdf_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lock = threading.Lock()
 _lib = None
@@ -86,6 +86,9 @@ def _load():
         for name in ("svbrdf_make_xrow", "svbrdf_render_fwd", "svbrdf_render_bwd", "svbrdf_rendering_loss_fwd_bwd",
                      "svbrdf_render_fwd_host_scenes", "svbrdf_render_bwd_host_scenes"):
             getattr(lib, name).restype = ctypes.c_int
+        lib.svbrdf_render_fwd_f64.argtypes = [_fp, _fp, _fp, _fp] + [ctypes.c_int] * 4 + [_fp]
+        lib.svbrdf_render_bwd_f64.argtypes = [_fp, _fp, _fp, _fp, _fp] + [ctypes.c_int] * 4 + [_fp]
+        lib.svbrdf_render_fwd_f64.restype = lib.svbrdf_render_bwd_f64.restype = ctypes.c_int
         v = lib.svbrdf_abi_version()
         if v != ABI_VERSION:
             raise NativeLibraryError("ABI mismatch: library %d, binding %d -- rebuild" % (v, ABI_VERSION))
@@ -195,11 +198,57 @@ def _scene_table_for_launch(scenes, device):
     return upload_scene_table(scenes, device), False
 
 
+def _require_device_float(t, name):
+    """float32 (the engine's path) or float64 (the reference's mixed-precision behaviour for double maps)"""
+    if isinstance(t, torch.Tensor) and t.dtype == torch.float64 and t.is_cuda:
+        return True
+    _require_device_f32(t, name)
+    return False
+
+
+def _scene_table_f64(maps, scenes):
+    """the float32 DEVICE table [B,S,9] the float64 entry points take (shared rows expanded per map)"""
+    B, S, H, W, shared = _dims(maps, scenes)
+    if scenes.dtype != torch.float32:
+        raise TypeError("scenes must be float32 (got %s): positions and colours are float32 in the reference whatever the "
+                        "maps' dtype (torch.Tensor(...), renderers.py:79,91,98)" % scenes.dtype)
+    if shared:
+        scenes = scenes.unsqueeze(0).expand(B, S, 9)
+    if scenes.is_cuda and scenes.device != maps.device:
+        raise ValueError("scenes are on %s, the maps on %s" % (scenes.device, maps.device))
+    return scenes.to(maps.device).contiguous(), B, S, H, W
+
+
+def _render_fwd_f64(maps, scenes):
+    table, B, S, H, W = _scene_table_f64(maps, scenes)
+    out = torch.empty((B, S, 3, H, W), dtype=torch.float64, device=maps.device)
+    with _on_device(maps.device):
+        _check(_load().svbrdf_render_fwd_f64(maps.data_ptr(), table.data_ptr(), xrow(maps.device, W).data_ptr(),
+                                             out.data_ptr(), B, S, H, W, _stream(maps.device)), "svbrdf_render_fwd_f64")
+    return out
+
+
+def _render_bwd_f64(maps, scenes, grad_out):
+    table, B, S, H, W = _scene_table_f64(maps, scenes)
+    if grad_out.dtype != torch.float64 or not grad_out.is_cuda:
+        raise TypeError("grad_out must be a float64 device tensor for float64 maps")
+    if grad_out.numel() != B * S * 3 * H * W or grad_out.shape[-2:] != maps.shape[-2:]:
+        raise ValueError("grad_out must be [B,S,3,H,W]")
+    grad = torch.empty_like(maps)
+    with _on_device(maps.device):
+        _check(_load().svbrdf_render_bwd_f64(maps.data_ptr(), table.data_ptr(), xrow(maps.device, W).data_ptr(),
+                                             grad_out.contiguous().data_ptr(), grad.data_ptr(), B, S, H, W,
+                                             _stream(maps.device)), "svbrdf_render_bwd_f64")
+    return grad
+
+
 def render_fwd(maps, scenes):
     """K1: maps [B,12,H,W]; scenes [B,S,9] on the device, or on the HOST as [B,S,9] / [S,9] (the same S scenes for
     every map): a host table of at most host_scenes_max_rows() rows travels with the launch (one dispatch, no copy
-    command).  -> renderings [B,S,3,H,W]."""
-    _require_device_f32(maps, "maps")
+    command).  -> renderings [B,S,3,H,W].  float64 maps take the mixed-precision path of the reference (float32
+    geometry, double shading: svbrdf_render_fwd_f64) and return float64."""
+    if _require_device_float(maps, "maps"):
+        return _render_fwd_f64(maps if maps.is_contiguous() else maps.contiguous(), scenes)
     if not maps.is_contiguous():
         maps = maps.contiguous()
     B, S, H, W, shared = _dims(maps, scenes)
@@ -221,7 +270,8 @@ def render_fwd(maps, scenes):
 
 def render_bwd(maps, scenes, grad_out):
     """K2: adjoint of render_fwd (same `scenes` forms) -> grad_maps [B,12,H,W]."""
-    _require_device_f32(maps, "maps")
+    if _require_device_float(maps, "maps"):
+        return _render_bwd_f64(maps if maps.is_contiguous() else maps.contiguous(), scenes, grad_out)
     _require_device_f32(grad_out, "grad_out")
     if not maps.is_contiguous():
         maps = maps.contiguous()

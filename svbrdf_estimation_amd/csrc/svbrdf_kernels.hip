@@ -1889,6 +1889,151 @@ void svbrdf_internal_launch_k3_adjoint_extra(SVBRDF_K3_ADJOINT_ARGS)
 #endif
 
 #if SVBRDF_TU_MAIN
+// ------------------------------------------------------------------------------------------
+// float64 maps.  The reference's render() is dtype-agnostic (renderers.py:67-104), but what it does with double maps is
+// MIXED precision: the pixel grid is torch.linspace's default float32 (:73) and camera / light positions and the light
+// colour go through torch.Tensor(...) = float32 (:79, :91, :98), so wo, wi, h, VH, (1-VH)^5 and colour * falloff are
+// computed in float32 exactly as for float32 maps, and only what touches the maps -- the dot products with the normal,
+// D, G, F, the BRDF, the radiance -- is promoted to double.  Same here: geometry() as above (float32, exact-rounded),
+// shading in double, op by op in the reference's order (no algebraic merging: this is the slow path of a caller who
+// asked for double -- gradient checks, notebooks -- not the training path).  K1 / K2 only; the losses compose them
+// through autograd (losses.py).  One pixel per thread.
+// ------------------------------------------------------------------------------------------
+namespace {
+constexpr double kPiD = 3.14159265358979323846;     // math.pi, renderers.py:20,27 (a python float: double in double ops)
+
+struct MapsD {
+    double n[3], d[3], r[3], s[3];
+};
+
+__device__ __forceinline__ void load_maps_f64(const double *__restrict__ base, size_t plane, size_t pix, MapsD &m)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        m.n[k] = base[(size_t)(0 + k) * plane + pix];
+        m.d[k] = base[(size_t)(3 + k) * plane + pix];
+        m.r[k] = base[(size_t)(6 + k) * plane + pix];
+        m.s[k] = base[(size_t)(9 + k) * plane + pix];
+    }
+}
+
+// torch.sum(a*b, dim=-3) with a double and b float32-valued: products in double, summed (p0+p1)+p2
+__device__ __forceinline__ double dot3d(const double a[3], double bx, double by, double bz)
+{
+    const double p0 = a[0] * bx, p1 = a[1] * by, p2 = a[2] * bz;
+    return (p0 + p1) + p2;
+}
+
+// forward of one (pixel, scene) in the reference's operation order; with grad_rad != nullptr also the adjoint, accumulated
+// into g (SURVEY.md section 8a's backward, PyTorch's sub-gradient conventions: clamp(min=m) passes iff x >= m)
+__device__ __forceinline__ void shade_f64(const Geom &g, const MapsD &m, double rad[3], const double *grad_rad, MapsD *acc)
+{
+    const double wo[3] = {g.wox, g.woy, g.woz}, wi[3] = {g.wix, g.wiy, g.wiz}, h[3] = {g.hx, g.hy, g.hz};
+    const double nh_raw = dot3d(m.n, h[0], h[1], h[2]);
+    const double vn_raw = dot3d(m.n, wo[0], wo[1], wo[2]);          // dot_product(wo, normals): the products commute
+    const double ln_raw = dot3d(m.n, wi[0], wi[1], wi[2]);
+    const double NH = fmax(nh_raw, 0.001), VN = fmax(vn_raw, 0.001), LN = fmax(ln_raw, 0.001), LNp = fmax(ln_raw, 0.0);
+    const double p = g.p;                                           // (1 - VH)^5, float32 (see the header above)
+    const double NH2 = NH * NH, VN2 = VN * VN, LN2 = LN * LN;
+    const double qV = (1.0 - VN2) / VN2, qL = (1.0 - LN2) / LN2, qN = (1.0 - NH2) / NH2;
+    const double four = 4.0 * VN * LN;
+    double g_VN = 0.0, g_LN = 0.0, g_NH = 0.0, g_LNp = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double r = fmax(m.r[k], 0.001);                       // renderers.py:87
+        const double a = r * r, A = a * a;                          // roughness**2, alpha**2
+        const double F = m.s[k] + (1.0 - m.s[k]) * p;               // :29-32
+        const double wV = sqrt(1.0 + A * qV), wL = sqrt(1.0 + A * qL);
+        const double G1V = 2.0 / (1.0 + wV), G1L = 2.0 / (1.0 + wL);   // xi() == 1: its arguments are clamped >= 1e-3
+        const double G = G1V * G1L;
+        const double den_raw = NH2 * (A + qN);
+        const double den = fmax(den_raw, 0.001);
+        const double D = A / (kPiD * (den * den));
+        const double spec = F * G * D / four;                       // :62
+        const double diff = (1.0 - F) * m.d[k] / kPiD;              // :18-20
+        const double f = diff + spec;
+        const double E = g.E[k];                                    // light colour * falloff, float32
+        rad[k] = (f * E) * LNp;                                     // :100
+        if (grad_rad) {
+            const double g_f = grad_rad[k] * E * LNp;
+            g_LNp += grad_rad[k] * f * E;
+            acc->d[k] += g_f * (1.0 - F) / kPiD;
+            const double g_F = g_f * (G * D / four - m.d[k] / kPiD);
+            acc->s[k] += g_F * (1.0 - p);
+            const double g_G = g_f * F * D / four, g_D = g_f * F * G / four;
+            g_VN -= g_f * spec / VN;                                // the 1/(4 VN LN) factor
+            g_LN -= g_f * spec / LN;
+            // G1 = 2/(1+w), w = sqrt(1 + A q):  dG1/dA = -q G1^2/(4w),  dG1/dq = -A G1^2/(4w)
+            const double dV = -G1V * G1V / (4.0 * wV), dL = -G1L * G1L / (4.0 * wL);
+            double g_A = g_G * (G1L * dV * qV + G1V * dL * qL);
+            const double g_qV = g_G * G1L * dV * A, g_qL = g_G * G1V * dL * A;
+            g_VN += g_qV * (-2.0 / (VN2 * VN));                     // q = (1 - X^2)/X^2 = X^-2 - 1
+            g_LN += g_qL * (-2.0 / (LN2 * LN));
+            // D = A/(pi den^2), den = clamp(NH^2 (A + (1-NH^2)/NH^2)) = clamp(NH^2 A + 1 - NH^2)
+            g_A += g_D / (kPiD * (den * den));
+            const double g_den = (den_raw >= 0.001) ? -2.0 * g_D * A / (kPiD * den * den * den) : 0.0;
+            g_A += g_den * NH2;
+            g_NH += g_den * (A - 1.0) * 2.0 * NH;
+            acc->r[k] += (m.r[k] >= 0.001) ? g_A * 4.0 * (a * r) : 0.0;
+        }
+    }
+    if (grad_rad) {
+        if (!(nh_raw >= 0.001)) g_NH = 0.0;
+        if (!(vn_raw >= 0.001)) g_VN = 0.0;
+        if (!(ln_raw >= 0.001)) g_LN = 0.0;
+        if (!(ln_raw >= 0.0)) g_LNp = 0.0;
+        const double gl = g_LN + g_LNp;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc->n[c] += g_NH * h[c] + g_VN * wo[c] + gl * wi[c];
+    }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(kThreads) void k_render_f64(const double *__restrict__ maps, const float *__restrict__ scenes,
+                                                         const float *__restrict__ xrow, const double *__restrict__ grad_out,
+                                                         double *__restrict__ out, int S, int H, int W)
+{
+    const size_t plane = (size_t)H * W;
+    const size_t pix = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    const int b = blockIdx.y;
+    if (pix >= plane) return;
+    MapsD m, acc;
+    load_maps_f64(maps + (size_t)b * 12 * plane, plane, pix, m);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc.n[k] = acc.d[k] = acc.r[k] = acc.s[k] = 0.0;
+    float x[1], y;
+    pixel_coords<1>(xrow, pix, W, x, y);
+    const VConst K = make_vconst();
+    for (int s = 0; s < S; ++s) {
+        float sc[9];
+        load_scene(scenes + ((size_t)b * S + s) * 9, sc);
+        const Geom g = geometry(K, sc, x[0], y);
+        double rad[3];
+        const size_t o = (((size_t)b * S + s) * 3) * plane + pix;
+        if (BWD) {
+            const double gr[3] = {grad_out[o], grad_out[o + plane], grad_out[o + 2 * plane]};
+            shade_f64(g, m, rad, gr, &acc);
+        } else {
+            shade_f64(g, m, rad, nullptr, nullptr);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out[o + (size_t)k * plane] = rad[k];
+        }
+    }
+    if (BWD) {
+        double *__restrict__ gm = out + (size_t)b * 12 * plane + pix;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gm[(size_t)(0 + k) * plane] = acc.n[k];
+            gm[(size_t)(3 + k) * plane] = acc.d[k];
+            gm[(size_t)(6 + k) * plane] = acc.r[k];
+            gm[(size_t)(9 + k) * plane] = acc.s[k];
+        }
+    }
+}
+}  // namespace
+#endif  // SVBRDF_TU_MAIN (float64 maps)
+
+#if SVBRDF_TU_MAIN
 extern "C" {
 
 int svbrdf_abi_version(void) { return SVBRDF_ABI_VERSION; }
@@ -2184,6 +2329,32 @@ int svbrdf_mix_materials(const float *svbrdf0, const float *svbrdf1, const float
     else if (vec == 2) hipLaunchKernelGGL(k_mix_materials<2>, grid, block, 0, st, svbrdf0, svbrdf1, alpha, out, plane);
     else hipLaunchKernelGGL(k_mix_materials<1>, grid, block, 0, st, svbrdf0, svbrdf1, alpha, out, plane);
     return launch_status("mix_materials launch");
+}
+
+static int render_f64_impl(bool bwd, const double *maps, const float *scenes, const float *xrow, const double *grad_out,
+                           double *out, int B, int S, int H, int W, void *stream)
+{
+    if (!maps || !scenes || !xrow || !out || (bwd && !grad_out)) return fail(SVBRDF_ERR_NULL, "render_f64: null pointer");
+    if (int e = check_dims(B, S, H, W)) return e;
+    if (!aligned(maps, 8) || !aligned(out, 8) || !aligned(scenes, 4) || !aligned(xrow, 4) || (bwd && !aligned(grad_out, 8)))
+        return fail(SVBRDF_ERR_ALIGN, "render_f64: double buffers must be 8-byte aligned, float buffers 4-byte");
+    const dim3 grid = grid_for(B, H, W, 1), block(kThreads);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bwd) hipLaunchKernelGGL(k_render_f64<true>, grid, block, 0, st, maps, scenes, xrow, grad_out, out, S, H, W);
+    else hipLaunchKernelGGL(k_render_f64<false>, grid, block, 0, st, maps, scenes, xrow, grad_out, out, S, H, W);
+    return launch_status(bwd ? "render_bwd_f64 launch" : "render_fwd_f64 launch");
+}
+
+int svbrdf_render_fwd_f64(const double *maps, const float *scenes, const float *xrow, double *out, int B, int S, int H, int W,
+                          void *stream)
+{
+    return render_f64_impl(false, maps, scenes, xrow, nullptr, out, B, S, H, W, stream);
+}
+
+int svbrdf_render_bwd_f64(const double *maps, const float *scenes, const float *xrow, const double *grad_out,
+                          double *grad_maps, int B, int S, int H, int W, void *stream)
+{
+    return render_f64_impl(true, maps, scenes, xrow, grad_out, grad_maps, B, S, H, W, stream);
 }
 
 int svbrdf_debug_clock_probe(unsigned long long *out_dev, unsigned long long ticks_100mhz, void *stream)

@@ -146,7 +146,27 @@ class RenderingLoss(nn.Module):
             return type(r).render is renderers.LocalRenderer.render and "render" not in vars(r)
         return _refcode.is_reference_local_renderer(r)
 
+    def _forward_double(self, input, target, l1_weight):
+        """float64 maps: the reference's loss (losses.py:29-52) is dtype-agnostic and, with double maps, mixed precision
+        (float32 geometry, double shading -- see svbrdf_render_fwd_f64).  Composed here from the float64 renders through
+        autograd: S renders per item in one K1 launch, log / L1 by torch in double, the backward through K2.  The slow
+        path of gradient checks and double-precision experiments; same scene draws as the fused path."""
+        _check_shapes(input, target)
+        if not input.is_cuda:
+            raise _native.NativeLibraryError("RenderingLoss needs tensors on a ROCm device (got %s); there is no CPU "
+                                             "fallback" % input.device)
+        target = target.to(torch.float64)
+        table = self.sample_scene_table(input.shape[0]).to(input.device)
+        a = torch.log(renderers._RenderFunction.apply(input, table) + self.epsilon_render)
+        t = torch.log(renderers._RenderFunction.apply(target, table) + self.epsilon_render)
+        loss = nn.functional.l1_loss(a, t)
+        if float(l1_weight) != 0.0:
+            loss = l1_weight * SVBRDFL1Loss()(input, target) + loss            # losses.py:62-63
+        return loss
+
     def _forward_fused(self, input, target, l1_weight=0.0, eps_l1=0.01, head=False):
+        if not head and input.dtype == torch.float64:
+            return self._forward_double(input, target, l1_weight)
         if head:
             if input.dim() != 4 or target.dim() != 4 or input.shape[1] != 9 or target.shape[1] != 12:
                 raise ValueError("head-fused loss needs input [B,9,H,W] and target [B,12,H,W]")

@@ -590,6 +590,54 @@ def g14_api():
     print("wrote g14_api.json")
 
 
+def _double_maps(seed, B, H, tiled=True):
+    """float64 maps that are NOT float32-representable: synth maps plus a 2^-30-scale perturbation, normals renormalised"""
+    m = synth.make_maps(seed, B, H, tiled_roughness=tiled).astype(np.float64)
+    jit = (synth.uniform01(seed * 7 + 3, m.shape).astype(np.float64) - 0.5) * 2.0 ** -29
+    m = m + jit
+    n = m[:, 0:3]
+    m[:, 0:3] = n / np.sqrt((n ** 2).sum(axis=1, keepdims=True))
+    m[:, 3:] = np.clip(m[:, 3:], 0.0, 1.0)
+    return m
+
+
+def g15_float64():
+    """Row b: LocalRenderer.render and RenderingLoss are dtype-agnostic in the reference (renderers.py:67-104,
+    losses.py:29-52).  With float64 maps the reference computes in mixed precision -- grid, positions and colours are
+    float32 (torch.linspace default dtype, torch.Tensor(...)), everything touching the maps is promoted to double.
+    Frozen here: renders of [2,12,16,16] double maps under a random, a specular and a grazing scene with the gradient
+    of a double cotangent, a roughness-below-clamp / back-facing edge patch, and RenderingLoss / MixedLoss with their
+    gradients on double inputs (scenes recorded)."""
+    out = {}
+    B, H = 2, 16
+    maps = _double_maps(151, B, H, tiled=False)
+    maps[0, 6:9, :2, :] = 0.0004                                     # roughness below the clamp (zero gradient there)
+    maps[1, 0:3, 3, :] = np.array([0.8, 0.0, -0.6])[:, None]         # back-facing normals (n.wi < 0 for frontal lights)
+    torch.manual_seed(21)
+    scenes = ref_env.generate_random_scenes(1) + ref_env.generate_specular_scenes(1) + [
+        ref_env.Scene(ref_env.Camera([1.5, -0.4, 0.05]), ref_env.Light([-0.7, 0.9, 0.6], [30.0, 20.0, 10.0]))]
+    R = ref_renderers.LocalRenderer()
+    x = torch.from_numpy(maps).clone().requires_grad_(True)
+    rend = torch.stack([R.render(sc, x) for sc in scenes], dim=1)     # [B,S,3,H,W]
+    assert rend.dtype == torch.float64
+    cot = (synth.uniform01(991, tuple(rend.shape)).astype(np.float64) - 0.5)
+    (rend * torch.from_numpy(cot)).sum().backward()
+    out.update(render_maps=maps, render_scenes=scene_table(scenes), render_out=rend.detach().numpy(), render_cot=cot,
+               render_grad=x.grad.numpy())
+    inp, tgt = _double_maps(161, B, H), _double_maps(162, B, H)
+    for name, fn in (("loss", ref_losses.RenderingLoss(ref_renderers.LocalRenderer())),
+                     ("mixed", ref_losses.MixedLoss(ref_renderers.LocalRenderer()))):
+        x = torch.from_numpy(inp).clone().requires_grad_(True)
+        torch.manual_seed(33)
+        with _Recorder() as rec:
+            val = fn(x, torch.from_numpy(tgt))
+        assert val.dtype == torch.float64
+        val.backward()
+        out.update({name + "_value": np.float64(val.item()), name + "_grad": x.grad.numpy(), name + "_scenes": rec.table()})
+    out.update(loss_input=inp, loss_target=tgt, loss_rng_seed=np.int64(33))
+    save("g15_float64.npz", **out)
+
+
 def g9_kat():
     R = ref_renderers.LocalRenderer()
     out = {}
@@ -633,6 +681,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--only-api":            # row b public surface, added in round 3
         g14_api()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-float64":        # row b dtype-agnostic render / loss, added in round 4
+        g15_float64()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-unet":           # row f4 network forward, added in round 2
         g13_unet_forward()
         return
@@ -652,6 +703,7 @@ def main():
     g12_dataset_reader()
     g13_unet_forward()
     g14_api()
+    g15_float64()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "mworchel/svbrdf-estimation @ /root/reference (development/multiImage_pytorch)",
