@@ -711,6 +711,7 @@ def main():
             "value": patches / elapsed, "unit": "patches/s", "n_gpus": world,
             "per_gpu_value": patches / elapsed / world,
             "value_through_autograd_engine": world * B / (engine_ms_per_step * 1e-3),
+            "valu_issue_frac": valu_issue["frac"] if valu_issue else None,      # what bounds K3 (also in roofline, with its inputs)
             "value_single_stream": world * B / (one["ms_per_step"] * 1e-3),
             "value_two_streams_overlapped": world * B / (two["ms_per_step"] * 1e-3),
             "value_note": ("`value` = the timed region, every step on ONE stream (what a training loop, serialised by its "

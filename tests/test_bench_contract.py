@@ -50,5 +50,5 @@ def test_bench_source_emits_the_contract_keys():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "workload", "roofline", "bound", "achieved", "peak", "frac", "traffic",
                 "cpu_baseline", "cores", "kind", "sample", "per_gpu_value", "value_through_autograd_engine", "valu_issue_frac",
-                "all_cores_patches_per_s", "shader_cycles_per_launch"):
+                "all_cores_patches_per_s", "shader_cycles_per_launch", "valu_issue_frac"):
         assert '"%s"' % key in src, key
