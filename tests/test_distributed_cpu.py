@@ -142,6 +142,26 @@ def test_bench_gpus_8_plumbing_as_the_scaling_run_starts_it():
     assert len(lines[0]["per_rank"]["cpus"]) == 8 and lines[0]["elapsed_max_over_ranks_s"] >= 0.08    # rank 7 sleeps 80 ms
 
 
+def test_bench_under_torch_distributed_run_as_the_driver_launches_it():
+    """the contract's N>1 form, word for word: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps K --warmup W`: the ranks come from the launcher's
+    environment (no self-spawn), rank 0 alone prints the line"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--backend", "gloo", "--plumbing-only"], env=_clean_env(), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    assert lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == 2 and lines[0]["launch"] == "external launcher"
+    assert len(lines[0]["per_rank"]["cpus"]) == 2
+
+
 def test_bench_refuses_a_world_that_is_not_gpus():
     """a launcher environment whose WORLD_SIZE contradicts --gpus must be an error, not a silent 1-rank run"""
     import subprocess
