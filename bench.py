@@ -702,6 +702,11 @@ def main():
                                       "instr_count_source": traffic_source,
                                       "achieved_wave_instr_per_s": rate, "peak_wave_instr_per_s": peak,
                                       "frac": rate / peak,
+                                      # a transcendental holds the SIMD for 6.5 plain issue slots when several waves share
+                                      # it (profiles/r01_valu_trans.txt: 4 rcp + 28 mul vs 32 mul, 4 waves per SIMD)
+                                      "frac_transcendental_weighted":
+                                          (rate / peak) * (1.0 + 5.5 * tj["trans_wave_instr_per_launch"] / tj["valu_wave_instr_per_launch"])
+                                          if tj.get("trans_wave_instr_per_launch") else None,
                                       "clock_GHz_under_load": clock_ghz, "clock_source": clock_note}
             except Exception:
                 traffic = valu_issue = traffic_source = None
