@@ -44,13 +44,15 @@ def miopen_cache_identity(cache_dir):
     with open(man, "rb") as f:
         raw = f.read()
     spec = json.loads(raw.decode())
-    pristine = True
+    changed = {}            # file -> bytes it grew by since the manifest (MIOpen appends find results and kernels), or "missing"
     for rel, want in spec.get("files", {}).items():
         path = os.path.join(cache_dir, rel)
         try:
             with open(path, "rb") as f:
-                pristine = pristine and hashlib.sha256(f.read()).hexdigest() == want["sha256"]
+                data = f.read()
+            if hashlib.sha256(data).hexdigest() != want["sha256"]:
+                changed[rel] = len(data) - want.get("bytes", 0)
         except OSError:
-            pristine = False
-    return {"in_tree": True, "manifest_sha256": hashlib.sha256(raw).hexdigest(), "files_match_manifest": pristine,
-            "miopen_build": spec.get("miopen_build")}
+            changed[rel] = "missing"
+    return {"in_tree": True, "manifest_sha256": hashlib.sha256(raw).hexdigest(), "files_match_manifest": not changed,
+            "files_grown_since_manifest_bytes": changed, "miopen_build": spec.get("miopen_build")}
