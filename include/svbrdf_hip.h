@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SVBRDF_ABI_VERSION 5
+#define SVBRDF_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define SVBRDF_API __attribute__((visibility("default")))
@@ -216,6 +216,20 @@ SVBRDF_API int svbrdf_render_fwd_f64(const double *maps, const float *scenes, co
                                      int B, int S, int H, int W, void *stream);
 SVBRDF_API int svbrdf_render_bwd_f64(const double *maps, const float *scenes, const float *xrow, const double *grad_out,
                                      double *grad_maps, int B, int S, int H, int W, void *stream);
+
+/* Second order (ABI version 6): what autograd needs to differentiate THROUGH the backward of render() -- the reference's
+ * render is built from differentiable torch ops (renderers.py:8-104), so `backward(create_graph=True)` /
+ * `torch.autograd.grad(..., create_graph=True)` work there (gradient penalties, Hessian-vector products in the notebooks'
+ * style of direct map optimisation).  For a direction `tangent` [B,12,H,W] of the maps, one forward-mode (dual number)
+ * evaluation of the float64 shading and its adjoint gives
+ *   out_tangent       [B,S,3,H,W] = J(maps) tangent                      (derivative of <J^T grad_out, tangent> w.r.t. grad_out)
+ *   grad_maps_tangent [B,12,H,W]  = d/dmaps <J(maps)^T grad_out, tangent>  (the Hessian of <grad_out, render(maps)> times tangent)
+ * with clamps and sub-gradient selections treated as torch's double-backward formulas treat them (masks compare values,
+ * zero derivative).  Buffers and error convention as svbrdf_render_bwd_f64; float32 callers are served by the host side
+ * through these in double. */
+SVBRDF_API int svbrdf_render_bwd_jvp_f64(const double *maps, const double *tangent, const float *scenes, const float *xrow,
+                                         const double *grad_out, double *grad_maps_tangent, double *out_tangent,
+                                         int B, int S, int H, int W, void *stream);
 
 #ifdef __cplusplus
 }

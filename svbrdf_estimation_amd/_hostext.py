@@ -56,5 +56,17 @@ def module():
     loader.exec_module(mod)
     _native._load()                       # make sure libsvbrdf_hip.so (and torch's HIP runtime) are in the process
     mod.bind(_native.library_path())
+    mod.set_second_order_hooks(_loss_second_order, _render_second_order)
     _mod = mod
     return _mod
+
+
+# what the extension's autograd nodes hand backward(create_graph=True) to (imported at call time: losses imports this module)
+def _loss_second_order(*args):
+    from . import losses
+    return losses.differentiable_loss_backward(*args)
+
+
+def _render_second_order(maps, scenes, grad_out):
+    from . import renderers
+    return renderers.differentiable_render_backward(maps, scenes, grad_out)

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SVBRDF_HIP_LIB: load another build of the same ABI (ablation/experiment builds of tools/); default in-tree
 _SO = os.environ.get("SVBRDF_HIP_LIB") or os.path.join(_HERE, "lib", "libsvbrdf_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lock = threading.Lock()
 _lib = None
@@ -89,6 +89,8 @@ def _load():
         lib.svbrdf_render_fwd_f64.argtypes = [_fp, _fp, _fp, _fp] + [ctypes.c_int] * 4 + [_fp]
         lib.svbrdf_render_bwd_f64.argtypes = [_fp, _fp, _fp, _fp, _fp] + [ctypes.c_int] * 4 + [_fp]
         lib.svbrdf_render_fwd_f64.restype = lib.svbrdf_render_bwd_f64.restype = ctypes.c_int
+        lib.svbrdf_render_bwd_jvp_f64.argtypes = [_fp] * 7 + [ctypes.c_int] * 4 + [_fp]
+        lib.svbrdf_render_bwd_jvp_f64.restype = ctypes.c_int
         v = lib.svbrdf_abi_version()
         if v != ABI_VERSION:
             raise NativeLibraryError("ABI mismatch: library %d, binding %d -- rebuild" % (v, ABI_VERSION))
@@ -240,6 +242,29 @@ def _render_bwd_f64(maps, scenes, grad_out):
                                              grad_out.contiguous().data_ptr(), grad.data_ptr(), B, S, H, W,
                                              _stream(maps.device)), "svbrdf_render_bwd_f64")
     return grad
+
+
+def render_bwd_jvp_f64(maps, tangent, scenes, grad_out):
+    """Second order (svbrdf_render_bwd_jvp_f64): for float64 ``maps`` [B,12,H,W], a direction ``tangent`` of the same
+    shape and ``grad_out`` [B,S,3,H,W] -> (d/dmaps <J^T grad_out, tangent> [B,12,H,W],  J tangent [B,S,3,H,W]): the two
+    products autograd needs to differentiate through the backward of ``render`` (create_graph=True)."""
+    for t, name in ((maps, "maps"), (tangent, "tangent"), (grad_out, "grad_out")):
+        if not (isinstance(t, torch.Tensor) and t.dtype == torch.float64 and t.is_cuda):
+            raise TypeError("%s must be a float64 tensor on a ROCm device" % name)
+    maps, tangent, grad_out = maps.contiguous(), tangent.contiguous(), grad_out.contiguous()
+    table, B, S, H, W = _scene_table_f64(maps, scenes)
+    if tangent.shape != maps.shape or tangent.device != maps.device:
+        raise ValueError("tangent must have the maps' shape and device")
+    if grad_out.numel() != B * S * 3 * H * W or grad_out.shape[-2:] != maps.shape[-2:] or grad_out.device != maps.device:
+        raise ValueError("grad_out must be [B,S,3,H,W] on the maps' device")
+    gm_t = torch.empty_like(maps)
+    out_t = torch.empty((B, S, 3, H, W), dtype=torch.float64, device=maps.device)
+    with _on_device(maps.device):
+        _check(_load().svbrdf_render_bwd_jvp_f64(maps.data_ptr(), tangent.data_ptr(), table.data_ptr(),
+                                                 xrow(maps.device, W).data_ptr(), grad_out.data_ptr(), gm_t.data_ptr(),
+                                                 out_t.data_ptr(), B, S, H, W, _stream(maps.device)),
+               "svbrdf_render_bwd_jvp_f64")
+    return gm_t, out_t
 
 
 def render_fwd(maps, scenes):

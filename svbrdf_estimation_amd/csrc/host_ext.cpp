@@ -273,6 +273,16 @@ struct State {
 // had used the pinned upload ring printed its result and then hung in teardown).
 State &g_state = *new State();
 
+// Second order.  backward(create_graph=True) runs a node's apply() with grad mode ON and expects a gradient that is itself
+// attached to the graph; the kernels' gradient buffers are constants to autograd.  The nodes below then hand the call to
+// the package's Python side (losses.differentiable_loss_backward, renderers.differentiable_render_backward: the same loss
+// composed from the float64 render kernels, whose backward has a dual-number companion kernel), registered here at import.
+// Never destroyed (like g_state): Python objects must not be released at static-destruction time.
+struct SecondOrderHooks {
+    pybind11::object loss, render;
+};
+SecondOrderHooks &g_hooks = *new SecondOrderHooks();
+
 // ------------------------------------------------------------------------------------------
 // autograd node: the kernel has already produced d loss / d input for upstream gradient 1.
 // A plain torch::autograd::Node (not the Function<> template: no AutogradContext, no saved_data dictionary of
@@ -282,9 +292,38 @@ struct FusedLossBackward : public torch::autograd::Node {
     at::Tensor grad_in, grad_tg;     // moved out by apply()
     bool has_in = false, has_tg = false, done = false;
     void *stream = nullptr;          // backward is enqueued on the forward's stream
+    // for backward(create_graph=True) only: the inputs (version-checked), the scene table and the loss's parameters
+    torch::autograd::SavedVariable input, target;
+    at::Tensor scenes_dev;
+    std::vector<float> scenes_host;
+    int64_t B = 0, S = 0;
+    double eps = 0.0, l1_weight = 0.0, eps_l1 = 0.0;
+    bool head = false;
+
+    torch::autograd::variable_list second_order(const at::Tensor &g0)
+    {
+        pybind11::gil_scoped_acquire gil;
+        TORCH_CHECK(g_hooks.loss && !g_hooks.loss.is_none(), "fused rendering loss: backward(create_graph=True) needs the "
+                                                               "package's second-order hook (import svbrdf_estimation_amd.losses)");
+        const auto in = input.unpack(shared_from_this()), tg = target.unpack(shared_from_this());
+        TORCH_CHECK(in.defined() && tg.defined(), "Trying to backward through the fused rendering loss a second time: its "
+                                                  "saved tensors were freed; specify retain_graph=True");
+        const at::Tensor sc = scenes_dev.defined()
+                                  ? scenes_dev
+                                  : at::from_blob(scenes_host.data(), {B, S, 9}, at::TensorOptions().dtype(at::kFloat)).clone();
+        const pybind11::tuple r = g_hooks.loss(in, tg, sc, eps, l1_weight, eps_l1, head, g0, has_in, has_tg);
+        torch::autograd::variable_list out(2);
+        if (!r[0].is_none()) out[0] = r[0].cast<at::Tensor>();
+        if (!r[1].is_none()) out[1] = r[1].cast<at::Tensor>();
+        return out;
+    }
 
     torch::autograd::variable_list apply(torch::autograd::variable_list &&grads) override
     {
+        if (at::GradMode::is_enabled()) {        // backward(create_graph=True)
+            TORCH_CHECK(grads[0].defined(), "fused rendering loss: undefined upstream gradient");
+            return second_order(grads[0]);
+        }
         TORCH_CHECK(!done, "Trying to backward through the fused rendering loss a second time: its gradient buffers were "
                            "handed to the first backward.  Specify retain_graph=True for that call (the buffers then stay "
                            "with the graph and each backward receives a scaled copy), as with any autograd graph "
@@ -319,6 +358,9 @@ struct FusedLossBackward : public torch::autograd::Node {
         done = true;
         grad_in.reset();
         grad_tg.reset();
+        input.reset_data();
+        target.reset_data();
+        scenes_dev.reset();
     }
 
     std::string name() const override { return "SvbrdfFusedLossBackward"; }
@@ -372,6 +414,13 @@ at::Tensor run_fused(const at::Tensor &input, const at::Tensor &target, const at
         node->has_in = need_in;
         node->has_tg = need_tg;
         node->stream = st;
+        node->input = torch::autograd::SavedVariable(input, false);
+        node->target = torch::autograd::SavedVariable(target, false);
+        node->B = scenes.size(0);
+        node->S = scenes.size(1);
+        if (host_table) node->scenes_host.assign(scenes.data_ptr<float>(), scenes.data_ptr<float>() + scenes.numel());
+        else node->scenes_dev = scenes;
+        node->eps = eps; node->l1_weight = l1_weight; node->eps_l1 = eps_l1; node->head = head;
         torch::autograd::set_history(loss, node);
     }
     return loss;
@@ -474,6 +523,14 @@ struct RenderBackward : public torch::autograd::Node {
         const auto m = maps.unpack(shared_from_this());
         TORCH_CHECK(m.defined(), "Trying to backward through LocalRenderer.render a second time: the saved maps were freed; "
                                  "specify retain_graph=True for the first backward");
+        if (at::GradMode::is_enabled() && grads[0].defined()) {        // backward(create_graph=True): see SecondOrderHooks
+            pybind11::gil_scoped_acquire gil;
+            TORCH_CHECK(g_hooks.render && !g_hooks.render.is_none(), "LocalRenderer.render: backward(create_graph=True) needs "
+                                                                       "the package's second-order hook");
+            const at::Tensor table = at::from_blob(rows.data(), {(int64_t)S, 9}, at::TensorOptions().dtype(at::kFloat)).clone();
+            out[0] = g_hooks.render(m, table, grads[0]).cast<at::Tensor>();
+            return out;
+        }
         at::AutoDispatchBelowADInplaceOrView below_autograd;
         if (!grads[0].defined()) {               // an undefined cotangent means zeros
             out[0] = at::zeros_like(m);
@@ -607,4 +664,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("sample_scene_table", &sample_scene_table);
     m.def("fast_backward", &fast_backward);
     m.def("render_shared_scenes", &render_shared_scenes);
+    m.def("set_second_order_hooks", [](pybind11::object loss, pybind11::object render) {
+        g_hooks.loss = std::move(loss);
+        g_hooks.render = std::move(render);
+    }, "callables the autograd nodes hand backward(create_graph=True) to (losses.differentiable_loss_backward, "
+       "renderers.differentiable_render_backward)");
 }

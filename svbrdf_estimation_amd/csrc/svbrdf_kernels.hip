@@ -1902,9 +1902,58 @@ void svbrdf_internal_launch_k3_adjoint_extra(SVBRDF_K3_ADJOINT_ARGS)
 namespace {
 constexpr double kPiD = 3.14159265358979323846;     // math.pi, renderers.py:20,27 (a python float: double in double ops)
 
-struct MapsD {
-    double n[3], d[3], r[3], s[3];
+// Scalar of the shading code: `double`, or `Dual` = value + directional derivative (forward-mode), which turns the
+// adjoint below into its own derivative along a direction u of the maps: the tangent of the rendering is J u and the
+// tangent of the accumulated gradient is d/dmaps <J^T grad_out, u> -- exactly the two products autograd needs to
+// differentiate THROUGH the backward of render() (create_graph=True; the reference gets them from plain autograd,
+// renderers.py:67-104 being built from differentiable ops).  Masks (clamps, sub-gradient selections) compare values and
+// have zero derivative, as in torch's double-backward formulas.
+struct Dual {
+    double v, d;
 };
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return Dual{a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Dual operator+(Dual a, double b) { return Dual{a.v + b, a.d}; }
+__device__ __forceinline__ Dual operator+(double a, Dual b) { return Dual{a + b.v, b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return Dual{a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, double b) { return Dual{a.v - b, a.d}; }
+__device__ __forceinline__ Dual operator-(double a, Dual b) { return Dual{a - b.v, -b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a) { return Dual{-a.v, -a.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return Dual{a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, double b) { return Dual{a.v * b, a.d * b}; }
+__device__ __forceinline__ Dual operator*(double a, Dual b) { return Dual{a * b.v, a * b.d}; }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b)
+{
+    const double q = a.v / b.v;
+    return Dual{q, (a.d - q * b.d) / b.v};
+}
+__device__ __forceinline__ Dual operator/(Dual a, double b) { return Dual{a.v / b, a.d / b}; }
+__device__ __forceinline__ Dual operator/(double a, Dual b)
+{
+    const double q = a / b.v;
+    return Dual{q, -q * b.d / b.v};
+}
+__device__ __forceinline__ Dual &operator+=(Dual &a, Dual b) { a.v += b.v; a.d += b.d; return a; }
+__device__ __forceinline__ Dual &operator-=(Dual &a, Dual b) { a.v -= b.v; a.d -= b.d; return a; }
+__device__ __forceinline__ double value_of(double x) { return x; }
+__device__ __forceinline__ double value_of(Dual x) { return x.v; }
+__device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+__device__ __forceinline__ Dual sqrt_(Dual x)
+{
+    const double r = sqrt(x.v);
+    return Dual{r, x.d / (2.0 * r)};
+}
+// torch.clamp(x, min=c): the gradient passes iff x >= c
+__device__ __forceinline__ double clamp_min(double x, double c) { return fmax(x, c); }
+__device__ __forceinline__ Dual clamp_min(Dual x, double c) { return x.v >= c ? x : Dual{c, 0.0}; }
+template <typename T> __device__ __forceinline__ T zero_of();
+template <> __device__ __forceinline__ double zero_of<double>() { return 0.0; }
+template <> __device__ __forceinline__ Dual zero_of<Dual>() { return Dual{0.0, 0.0}; }
+
+template <typename T>
+struct MapsT {
+    T n[3], d[3], r[3], s[3];
+};
+using MapsD = MapsT<double>;
 
 __device__ __forceinline__ void load_maps_f64(const double *__restrict__ base, size_t plane, size_t pix, MapsD &m)
 {
@@ -1918,71 +1967,73 @@ __device__ __forceinline__ void load_maps_f64(const double *__restrict__ base, s
 }
 
 // torch.sum(a*b, dim=-3) with a double and b float32-valued: products in double, summed (p0+p1)+p2
-__device__ __forceinline__ double dot3d(const double a[3], double bx, double by, double bz)
+template <typename T>
+__device__ __forceinline__ T dot3d(const T a[3], double bx, double by, double bz)
 {
-    const double p0 = a[0] * bx, p1 = a[1] * by, p2 = a[2] * bz;
+    const T p0 = a[0] * bx, p1 = a[1] * by, p2 = a[2] * bz;
     return (p0 + p1) + p2;
 }
 
 // forward of one (pixel, scene) in the reference's operation order; with grad_rad != nullptr also the adjoint, accumulated
 // into g (SURVEY.md section 8a's backward, PyTorch's sub-gradient conventions: clamp(min=m) passes iff x >= m)
-__device__ __forceinline__ void shade_f64(const Geom &g, const MapsD &m, double rad[3], const double *grad_rad, MapsD *acc)
+template <typename T>
+__device__ __forceinline__ void shade_f64(const Geom &g, const MapsT<T> &m, T rad[3], const T *grad_rad, MapsT<T> *acc)
 {
     const double wo[3] = {g.wox, g.woy, g.woz}, wi[3] = {g.wix, g.wiy, g.wiz}, h[3] = {g.hx, g.hy, g.hz};
-    const double nh_raw = dot3d(m.n, h[0], h[1], h[2]);
-    const double vn_raw = dot3d(m.n, wo[0], wo[1], wo[2]);          // dot_product(wo, normals): the products commute
-    const double ln_raw = dot3d(m.n, wi[0], wi[1], wi[2]);
-    const double NH = fmax(nh_raw, 0.001), VN = fmax(vn_raw, 0.001), LN = fmax(ln_raw, 0.001), LNp = fmax(ln_raw, 0.0);
+    const T nh_raw = dot3d(m.n, h[0], h[1], h[2]);
+    const T vn_raw = dot3d(m.n, wo[0], wo[1], wo[2]);               // dot_product(wo, normals): the products commute
+    const T ln_raw = dot3d(m.n, wi[0], wi[1], wi[2]);
+    const T NH = clamp_min(nh_raw, 0.001), VN = clamp_min(vn_raw, 0.001), LN = clamp_min(ln_raw, 0.001), LNp = clamp_min(ln_raw, 0.0);
     const double p = g.p;                                           // (1 - VH)^5, float32 (see the header above)
-    const double NH2 = NH * NH, VN2 = VN * VN, LN2 = LN * LN;
-    const double qV = (1.0 - VN2) / VN2, qL = (1.0 - LN2) / LN2, qN = (1.0 - NH2) / NH2;
-    const double four = 4.0 * VN * LN;
-    double g_VN = 0.0, g_LN = 0.0, g_NH = 0.0, g_LNp = 0.0;
+    const T NH2 = NH * NH, VN2 = VN * VN, LN2 = LN * LN;
+    const T qV = (1.0 - VN2) / VN2, qL = (1.0 - LN2) / LN2, qN = (1.0 - NH2) / NH2;
+    const T four = 4.0 * VN * LN;
+    T g_VN = zero_of<T>(), g_LN = zero_of<T>(), g_NH = zero_of<T>(), g_LNp = zero_of<T>();
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const double r = fmax(m.r[k], 0.001);                       // renderers.py:87
-        const double a = r * r, A = a * a;                          // roughness**2, alpha**2
-        const double F = m.s[k] + (1.0 - m.s[k]) * p;               // :29-32
-        const double wV = sqrt(1.0 + A * qV), wL = sqrt(1.0 + A * qL);
-        const double G1V = 2.0 / (1.0 + wV), G1L = 2.0 / (1.0 + wL);   // xi() == 1: its arguments are clamped >= 1e-3
-        const double G = G1V * G1L;
-        const double den_raw = NH2 * (A + qN);
-        const double den = fmax(den_raw, 0.001);
-        const double D = A / (kPiD * (den * den));
-        const double spec = F * G * D / four;                       // :62
-        const double diff = (1.0 - F) * m.d[k] / kPiD;              // :18-20
-        const double f = diff + spec;
+        const T r = clamp_min(m.r[k], 0.001);                       // renderers.py:87
+        const T a = r * r, A = a * a;                               // roughness**2, alpha**2
+        const T F = m.s[k] + (1.0 - m.s[k]) * p;                    // :29-32
+        const T wV = sqrt_(1.0 + A * qV), wL = sqrt_(1.0 + A * qL);
+        const T G1V = 2.0 / (1.0 + wV), G1L = 2.0 / (1.0 + wL);     // xi() == 1: its arguments are clamped >= 1e-3
+        const T G = G1V * G1L;
+        const T den_raw = NH2 * (A + qN);
+        const T den = clamp_min(den_raw, 0.001);
+        const T D = A / (kPiD * (den * den));
+        const T spec = F * G * D / four;                            // :62
+        const T diff = (1.0 - F) * m.d[k] / kPiD;                   // :18-20
+        const T f = diff + spec;
         const double E = g.E[k];                                    // light colour * falloff, float32
         rad[k] = (f * E) * LNp;                                     // :100
         if (grad_rad) {
-            const double g_f = grad_rad[k] * E * LNp;
+            const T g_f = grad_rad[k] * E * LNp;
             g_LNp += grad_rad[k] * f * E;
             acc->d[k] += g_f * (1.0 - F) / kPiD;
-            const double g_F = g_f * (G * D / four - m.d[k] / kPiD);
+            const T g_F = g_f * (G * D / four - m.d[k] / kPiD);
             acc->s[k] += g_F * (1.0 - p);
-            const double g_G = g_f * F * D / four, g_D = g_f * F * G / four;
+            const T g_G = g_f * F * D / four, g_D = g_f * F * G / four;
             g_VN -= g_f * spec / VN;                                // the 1/(4 VN LN) factor
             g_LN -= g_f * spec / LN;
             // G1 = 2/(1+w), w = sqrt(1 + A q):  dG1/dA = -q G1^2/(4w),  dG1/dq = -A G1^2/(4w)
-            const double dV = -G1V * G1V / (4.0 * wV), dL = -G1L * G1L / (4.0 * wL);
-            double g_A = g_G * (G1L * dV * qV + G1V * dL * qL);
-            const double g_qV = g_G * G1L * dV * A, g_qL = g_G * G1V * dL * A;
+            const T dV = -G1V * G1V / (4.0 * wV), dL = -G1L * G1L / (4.0 * wL);
+            T g_A = g_G * (G1L * dV * qV + G1V * dL * qL);
+            const T g_qV = g_G * G1L * dV * A, g_qL = g_G * G1V * dL * A;
             g_VN += g_qV * (-2.0 / (VN2 * VN));                     // q = (1 - X^2)/X^2 = X^-2 - 1
             g_LN += g_qL * (-2.0 / (LN2 * LN));
             // D = A/(pi den^2), den = clamp(NH^2 (A + (1-NH^2)/NH^2)) = clamp(NH^2 A + 1 - NH^2)
             g_A += g_D / (kPiD * (den * den));
-            const double g_den = (den_raw >= 0.001) ? -2.0 * g_D * A / (kPiD * den * den * den) : 0.0;
+            const T g_den = (value_of(den_raw) >= 0.001) ? -2.0 * g_D * A / (kPiD * den * den * den) : zero_of<T>();
             g_A += g_den * NH2;
             g_NH += g_den * (A - 1.0) * 2.0 * NH;
-            acc->r[k] += (m.r[k] >= 0.001) ? g_A * 4.0 * (a * r) : 0.0;
+            acc->r[k] += (value_of(m.r[k]) >= 0.001) ? g_A * 4.0 * (a * r) : zero_of<T>();
         }
     }
     if (grad_rad) {
-        if (!(nh_raw >= 0.001)) g_NH = 0.0;
-        if (!(vn_raw >= 0.001)) g_VN = 0.0;
-        if (!(ln_raw >= 0.001)) g_LN = 0.0;
-        if (!(ln_raw >= 0.0)) g_LNp = 0.0;
-        const double gl = g_LN + g_LNp;
+        if (!(value_of(nh_raw) >= 0.001)) g_NH = zero_of<T>();
+        if (!(value_of(vn_raw) >= 0.001)) g_VN = zero_of<T>();
+        if (!(value_of(ln_raw) >= 0.001)) g_LN = zero_of<T>();
+        if (!(value_of(ln_raw) >= 0.0)) g_LNp = zero_of<T>();
+        const T gl = g_LN + g_LNp;
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc->n[c] += g_NH * h[c] + g_VN * wo[c] + gl * wi[c];
     }
@@ -2012,9 +2063,9 @@ __global__ __launch_bounds__(kThreads) void k_render_f64(const double *__restric
         const size_t o = (((size_t)b * S + s) * 3) * plane + pix;
         if (BWD) {
             const double gr[3] = {grad_out[o], grad_out[o + plane], grad_out[o + 2 * plane]};
-            shade_f64(g, m, rad, gr, &acc);
+            shade_f64<double>(g, m, rad, gr, &acc);
         } else {
-            shade_f64(g, m, rad, nullptr, nullptr);
+            shade_f64<double>(g, m, rad, nullptr, nullptr);
 #pragma unroll
             for (int k = 0; k < 3; ++k) out[o + (size_t)k * plane] = rad[k];
         }
@@ -2028,6 +2079,51 @@ __global__ __launch_bounds__(kThreads) void k_render_f64(const double *__restric
             gm[(size_t)(6 + k) * plane] = acc.r[k];
             gm[(size_t)(9 + k) * plane] = acc.s[k];
         }
+    }
+}
+// Derivative of the render's backward along a direction `tangent` of the maps (see Dual): per pixel, S dual-number
+// evaluations of shade_f64.  grad_maps_tangent [B,12,H,W] = d/dmaps <J^T grad_out, tangent>; out_tangent [B,S,3,H,W] = J tangent.
+__global__ __launch_bounds__(kThreads) void k_render_f64_jvp(const double *__restrict__ maps, const double *__restrict__ tangent,
+                                                             const float *__restrict__ scenes, const float *__restrict__ xrow,
+                                                             const double *__restrict__ grad_out,
+                                                             double *__restrict__ grad_maps_tangent,
+                                                             double *__restrict__ out_tangent, int S, int H, int W)
+{
+    const size_t plane = (size_t)H * W;
+    const size_t pix = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    const int b = blockIdx.y;
+    if (pix >= plane) return;
+    MapsD mv, mt;
+    load_maps_f64(maps + (size_t)b * 12 * plane, plane, pix, mv);
+    load_maps_f64(tangent + (size_t)b * 12 * plane, plane, pix, mt);
+    MapsT<Dual> m, acc;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        m.n[k] = Dual{mv.n[k], mt.n[k]}; m.d[k] = Dual{mv.d[k], mt.d[k]};
+        m.r[k] = Dual{mv.r[k], mt.r[k]}; m.s[k] = Dual{mv.s[k], mt.s[k]};
+        acc.n[k] = acc.d[k] = acc.r[k] = acc.s[k] = Dual{0.0, 0.0};
+    }
+    float x[1], y;
+    pixel_coords<1>(xrow, pix, W, x, y);
+    const VConst K = make_vconst();
+    for (int s = 0; s < S; ++s) {
+        float sc[9];
+        load_scene(scenes + ((size_t)b * S + s) * 9, sc);
+        const Geom g = geometry(K, sc, x[0], y);
+        const size_t o = (((size_t)b * S + s) * 3) * plane + pix;
+        const Dual gr[3] = {Dual{grad_out[o], 0.0}, Dual{grad_out[o + plane], 0.0}, Dual{grad_out[o + 2 * plane], 0.0}};
+        Dual rad[3];
+        shade_f64<Dual>(g, m, rad, gr, &acc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out_tangent[o + (size_t)k * plane] = rad[k].d;
+    }
+    double *__restrict__ gm = grad_maps_tangent + (size_t)b * 12 * plane + pix;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gm[(size_t)(0 + k) * plane] = acc.n[k].d;
+        gm[(size_t)(3 + k) * plane] = acc.d[k].d;
+        gm[(size_t)(6 + k) * plane] = acc.r[k].d;
+        gm[(size_t)(9 + k) * plane] = acc.s[k].d;
     }
 }
 }  // namespace
@@ -2355,6 +2451,22 @@ int svbrdf_render_bwd_f64(const double *maps, const float *scenes, const float *
                           double *grad_maps, int B, int S, int H, int W, void *stream)
 {
     return render_f64_impl(true, maps, scenes, xrow, grad_out, grad_maps, B, S, H, W, stream);
+}
+
+int svbrdf_render_bwd_jvp_f64(const double *maps, const double *tangent, const float *scenes, const float *xrow,
+                              const double *grad_out, double *grad_maps_tangent, double *out_tangent, int B, int S, int H, int W,
+                              void *stream)
+{
+    if (!maps || !tangent || !scenes || !xrow || !grad_out || !grad_maps_tangent || !out_tangent)
+        return fail(SVBRDF_ERR_NULL, "render_bwd_jvp_f64: null pointer");
+    if (int e = check_dims(B, S, H, W)) return e;
+    if (!aligned(maps, 8) || !aligned(tangent, 8) || !aligned(grad_out, 8) || !aligned(grad_maps_tangent, 8) ||
+        !aligned(out_tangent, 8) || !aligned(scenes, 4) || !aligned(xrow, 4))
+        return fail(SVBRDF_ERR_ALIGN, "render_bwd_jvp_f64: double buffers must be 8-byte aligned, float buffers 4-byte");
+    const dim3 grid = grid_for(B, H, W, 1), block(kThreads);
+    hipLaunchKernelGGL(k_render_f64_jvp, grid, block, 0, static_cast<hipStream_t>(stream), maps, tangent, scenes, xrow, grad_out,
+                       grad_maps_tangent, out_tangent, S, H, W);
+    return launch_status("render_bwd_jvp_f64 launch");
 }
 
 int svbrdf_debug_clock_probe(unsigned long long *out_dev, unsigned long long ticks_100mhz, void *stream)

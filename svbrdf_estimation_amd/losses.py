@@ -38,6 +38,9 @@ class _FusedRenderingLoss(torch.autograd.Function):
         need_tg = ctx.needs_input_grad[1]
         if head and need_tg:
             raise RuntimeError("the head-fused loss has no gradient w.r.t. the target maps")
+        # (kept for backward(create_graph=True) only: references, no copies; a host table is a few hundred floats)
+        ctx.save_for_backward(input, target)
+        ctx.second_order = (scenes if scenes.is_cuda else scenes.detach().clone(), float(eps), float(l1_weight), float(eps_l1), bool(head))
         loss, grad_in = _native.rendering_loss(input, target, scenes, eps, want_grad=need_in,
                                                l1_weight=l1_weight, eps_l1=eps_l1, head=head)
         grad_tg = None
@@ -53,6 +56,12 @@ class _FusedRenderingLoss(torch.autograd.Function):
         if ctx.grads is None:
             raise RuntimeError("Trying to backward through the fused rendering loss a second time: its gradient buffers "
                                "were handed to the first backward.  Specify retain_graph=True for the first one.")
+        if torch.is_grad_enabled():
+            # backward(create_graph=True): the kernel's gradient buffers are constants to autograd; recompute the loss
+            # from differentiable pieces instead (same scenes) and let autograd derive a gradient it can differentiate
+            input, target = ctx.saved_tensors
+            return differentiable_loss_backward(input, target, *ctx.second_order, grad_loss,
+                                                ctx.needs_input_grad[0], ctx.needs_input_grad[1]) + (None,) * 5
         grad_in, grad_tg = ctx.grads
         # chain rule through the scalar loss on the device (no host sync).  This is the FALLBACK host path (the native
         # extension is the default and does the same in csrc/host_ext.cpp): a plain backward hands the kernel's buffers
@@ -67,6 +76,37 @@ class _FusedRenderingLoss(torch.autograd.Function):
         for g in (grad_in, grad_tg):
             outs.append(None if g is None else _native.scale_inplace_(g.clone() if keep else g, scale))
         return outs[0], outs[1], None, None, None, None, None
+
+
+def composed_loss(input, target, scenes, eps, l1_weight=0.0, eps_l1=0.01, head=False):
+    """The fused kernel's loss -- losses.py:29-52, plus ``l1_weight`` x losses.py:7-19 and the head decode of
+    models.py:338-346 when asked for -- from differentiable pieces in float64: S renders per item through the float64
+    K1 / K2 (``renderers._RenderFunction``), log / L1 by torch.  What float64 inputs take, and what
+    ``backward(create_graph=True)`` of the fused float32 loss differentiates (the fused kernel's own gradient is a constant
+    to autograd).  ``scenes`` [B,S,9] float32, host or device."""
+    x, t = input.to(torch.float64), target.to(torch.float64)
+    maps = decode_head(x) if head else x
+    a = torch.log(renderers._RenderFunction.apply(maps, scenes) + eps)
+    b = torch.log(renderers._RenderFunction.apply(t, scenes) + eps)
+    loss = nn.functional.l1_loss(a, b)
+    if float(l1_weight) != 0.0:
+        l1 = SVBRDFL1Loss()
+        l1.epsilon_l1 = eps_l1
+        loss = l1_weight * l1(maps, t) + loss                                  # losses.py:62-63
+    return loss
+
+
+def differentiable_loss_backward(input, target, scenes, eps, l1_weight, eps_l1, head, grad_loss, need_in=True, need_tg=False):
+    """(d loss/d input, d loss/d target) x ``grad_loss`` for the fused loss, attached to the autograd graph: the answer
+    to ``backward(create_graph=True)`` / ``torch.autograd.grad(..., create_graph=True)``.  Also the entry point the native
+    host extension calls back into (csrc/host_ext.cpp)."""
+    with torch.enable_grad():
+        loss = composed_loss(input, target, scenes, eps, l1_weight, eps_l1, head)
+        wanted = [t for t, need in ((input, need_in), (target, need_tg)) if need]
+        grads = list(torch.autograd.grad(loss, wanted, grad_loss.to(torch.float64).reshape(()), create_graph=True))
+    g_in = grads.pop(0).to(input.dtype) if need_in else None
+    g_tg = grads.pop(0).to(target.dtype) if need_tg else None
+    return g_in, g_tg
 
 
 def _fast_backward_enabled():
@@ -155,14 +195,8 @@ class RenderingLoss(nn.Module):
         if not input.is_cuda:
             raise _native.NativeLibraryError("RenderingLoss needs tensors on a ROCm device (got %s); there is no CPU "
                                              "fallback" % input.device)
-        target = target.to(torch.float64)
         table = self.sample_scene_table(input.shape[0]).to(input.device)
-        a = torch.log(renderers._RenderFunction.apply(input, table) + self.epsilon_render)
-        t = torch.log(renderers._RenderFunction.apply(target, table) + self.epsilon_render)
-        loss = nn.functional.l1_loss(a, t)
-        if float(l1_weight) != 0.0:
-            loss = l1_weight * SVBRDFL1Loss()(input, target) + loss            # losses.py:62-63
-        return loss
+        return composed_loss(input, target, table, self.epsilon_render, l1_weight)
 
     def _forward_fused(self, input, target, l1_weight=0.0, eps_l1=0.01, head=False):
         if not head and input.dtype == torch.float64:

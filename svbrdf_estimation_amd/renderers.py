@@ -40,7 +40,60 @@ class _RenderFunction(torch.autograd.Function):
             return None, None
         saved = ctx.saved_tensors
         scenes = ctx.host_scenes if ctx.host_scenes is not None else saved[1]
+        if torch.is_grad_enabled():
+            # backward(create_graph=True): the gradient must itself be differentiable, as it is through the reference's
+            # op-by-op render (renderers.py:67-104)
+            return differentiable_render_backward(saved[0], scenes, grad_out), None
         return _native.render_bwd(saved[0], scenes, grad_out), None
+
+
+class _RenderBackwardF64(torch.autograd.Function):
+    """``J(maps)^T grad_out`` in float64 (K2's float64 form) as a node that can be differentiated once more: its backward is
+    the dual-number kernel ``svbrdf_render_bwd_jvp_f64``.  maps [B,12,H,W], grad_out [B,S,3,H,W] double; scenes [B,S,9]
+    float32 on the device."""
+
+    @staticmethod
+    def forward(ctx, maps, grad_out, scenes):
+        ctx.save_for_backward(maps, grad_out, scenes)
+        return _native.render_bwd(maps, scenes, grad_out)
+
+    @staticmethod
+    def backward(ctx, tangent):
+        maps, grad_out, scenes = ctx.saved_tensors
+        third = torch.is_grad_enabled()                   # create_graph=True on the SECOND-order call
+        with torch.no_grad():
+            grad_maps_t, out_t = _native.render_bwd_jvp_f64(maps, tangent, scenes, grad_out)
+        if third:
+            # there is no third-order kernel: an error when someone differentiates these, never silent constants
+            # (torch's once_differentiable only guards against a tangent that requires grad, not against the saved maps)
+            grad_maps_t = _NoThirdOrder.apply(grad_maps_t, maps, grad_out, tangent)
+            out_t = _NoThirdOrder.apply(out_t, maps, grad_out, tangent)
+        return (grad_maps_t if ctx.needs_input_grad[0] else None), (out_t if ctx.needs_input_grad[1] else None), None
+
+
+class _NoThirdOrder(torch.autograd.Function):
+    """identity whose derivative is an error: marks the second-order results as depending on the maps, the cotangent and
+    the direction without offering a derivative"""
+
+    @staticmethod
+    def forward(ctx, value, *depends_on):
+        return value.view_as(value)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise RuntimeError("third-order derivatives of LocalRenderer.render are not implemented by the MI355X engine "
+                           "(first order: K2 / K3; second order: svbrdf_render_bwd_jvp_f64)")
+
+
+def differentiable_render_backward(maps, scenes, grad_out):
+    """The gradient of ``render`` w.r.t. ``maps`` for upstream ``grad_out``, attached to the autograd graph of both (what
+    ``create_graph=True`` asks for).  Computed in float64 whatever the maps' dtype (the float32 kernels K1/K2/K3 have no
+    second-order companion; float32 maps are promoted exactly) and returned in the maps' dtype.  Also the entry point the
+    native host extension calls back into (csrc/host_ext.cpp) when its nodes run under create_graph=True."""
+    table = _native._scene_table_f64(maps, scenes)[0]
+    grad = _RenderBackwardF64.apply(maps.to(torch.float64), grad_out.reshape(table.shape[0], table.shape[1], 3, *maps.shape[-2:])
+                                    .to(torch.float64), table)
+    return grad.to(maps.dtype)
 
 
 class LocalRenderer:

@@ -638,6 +638,55 @@ def g15_float64():
     save("g15_float64.npz", **out)
 
 
+def g16_second_order():
+    """Row b, second order: the reference's render and losses are built from differentiable torch ops, so
+    ``backward(create_graph=True)`` / ``torch.autograd.grad(..., create_graph=True)`` work through them (renderers.py:67-104,
+    losses.py:29-52).  Frozen here, all in float64 (the reference's mixed precision for double maps):
+      * render: maps [2,12,12,12] with the edge rows of g15, three scenes, a cotangent c and a direction v ->
+        g = d<c, render(x)>/dx, then d<g, v>/dx (Hessian-vector product) and d<g, v>/dc (= J v);
+      * RenderingLoss and MixedLoss on double inputs: g = dL/dx, the gradient of the penalty sum(g^2) w.r.t. x, and the
+        Hessian-vector product d<g, v>/dx (scenes recorded);
+      * the same two losses on float32-VALUED inputs evaluated in double ("f32v_*"): what a float32 caller's
+        create_graph=True is compared with (the engine promotes such a call to double)."""
+    out = {}
+    B, H = 2, 12
+    maps = _double_maps(171, B, H, tiled=False)
+    maps[0, 6:9, :2, :] = 0.0004                                     # roughness below the clamp
+    maps[1, 0:3, 3, :] = np.array([0.8, 0.0, -0.6])[:, None]         # back-facing normals
+    torch.manual_seed(23)
+    scenes = ref_env.generate_random_scenes(1) + ref_env.generate_specular_scenes(1) + [
+        ref_env.Scene(ref_env.Camera([1.5, -0.4, 0.05]), ref_env.Light([-0.7, 0.9, 0.6], [30.0, 20.0, 10.0]))]
+    R = ref_renderers.LocalRenderer()
+    x = torch.from_numpy(maps).clone().requires_grad_(True)
+    rend = torch.stack([R.render(sc, x) for sc in scenes], dim=1)     # [B,S,3,H,W]
+    cot = torch.from_numpy(synth.uniform01(993, tuple(rend.shape)).astype(np.float64) - 0.5).requires_grad_(True)
+    v = synth.uniform01(995, maps.shape).astype(np.float64) - 0.5
+    (g,) = torch.autograd.grad((rend * cot).sum(), x, create_graph=True)
+    hv, jv = torch.autograd.grad((g * torch.from_numpy(v)).sum(), (x, cot))
+    out.update(render_maps=maps, render_scenes=scene_table(scenes), render_cot=cot.detach().numpy(), render_v=v,
+               render_grad=g.detach().numpy(), render_hvp=hv.numpy(), render_jv=jv.numpy())
+    inp, tgt = _double_maps(181, B, H), _double_maps(182, B, H)
+    inp32 = synth.make_maps(183, B, H).astype(np.float64)            # float32-valued
+    tgt32 = synth.make_maps(184, B, H).astype(np.float64)
+    vl = synth.uniform01(997, inp.shape).astype(np.float64) - 0.5
+    for tag, a, b in (("", inp, tgt), ("f32v_", inp32, tgt32)):
+        for name, fn in (("loss", ref_losses.RenderingLoss(ref_renderers.LocalRenderer())),
+                         ("mixed", ref_losses.MixedLoss(ref_renderers.LocalRenderer()))):
+            x = torch.from_numpy(a).clone().requires_grad_(True)
+            torch.manual_seed(35)
+            with _Recorder() as rec:
+                val = fn(x, torch.from_numpy(b))
+            (g,) = torch.autograd.grad(val, x, create_graph=True)
+            (pen,) = torch.autograd.grad((g ** 2).sum(), x, retain_graph=True)
+            (hv,) = torch.autograd.grad((g * torch.from_numpy(vl)).sum(), x)
+            out.update({tag + name + "_value": np.float64(val.item()), tag + name + "_grad": g.detach().numpy(),
+                        tag + name + "_penalty_grad": pen.numpy(), tag + name + "_hvp": hv.numpy(),
+                        tag + name + "_scenes": rec.table()})
+    out.update(loss_input=inp, loss_target=tgt, f32v_loss_input=inp32, f32v_loss_target=tgt32, loss_v=vl,
+               loss_rng_seed=np.int64(35))
+    save("g16_second_order.npz", **out)
+
+
 def g9_kat():
     R = ref_renderers.LocalRenderer()
     out = {}
@@ -684,6 +733,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--only-float64":        # row b dtype-agnostic render / loss, added in round 4
         g15_float64()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-second-order":   # row b create_graph=True, added in round 4
+        g16_second_order()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-unet":           # row f4 network forward, added in round 2
         g13_unet_forward()
         return
@@ -704,6 +756,7 @@ def main():
     g13_unet_forward()
     g14_api()
     g15_float64()
+    g16_second_order()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "mworchel/svbrdf-estimation @ /root/reference (development/multiImage_pytorch)",

@@ -148,3 +148,28 @@ def test_head_decode_and_head_loss(oracle, golden):
         _, g64 = oracle.head_loss(g["enc9"], g["target"], g["scenes"], w, f64=True)
         assert_loss_close(loss, g[tag + "_loss"], tag)
         assert_grad_close(grad, g[tag + "_grad9"], tag + " grad9", f64=g64)
+
+
+def test_eager_restatement_against_the_reference_first_and_second_order(golden):
+    """oracle/eager_torch.py -- the reference's algorithm as eager PyTorch, which bench.py times as the CPU baseline -- on
+    the reference's own outputs: the float32 loss and gradient of g3, and in float64 (the reference's mixed precision for
+    double maps) the second-order fixture g16: gradient under create_graph, gradient of the penalty sum(g^2), Hessian-
+    vector product.  Same ops on the same machine class: the float64 results agree to rounding."""
+    import torch
+    from oracle import eager_torch
+    g = golden("g3_loss_48.npz")
+    x = torch.from_numpy(g["input"]).clone().requires_grad_(True)
+    loss = eager_torch.rendering_loss(x, torch.from_numpy(g["target"]), torch.from_numpy(g["scenes"]))
+    loss.backward()
+    assert_loss_close(loss.item(), g["loss"], "eager loss")
+    assert_grad_close(x.grad.numpy(), g["grad_input"], "eager grad_input")
+    s = golden("g16_second_order.npz")
+    x = torch.from_numpy(s["loss_input"]).clone().requires_grad_(True)
+    val = eager_torch.rendering_loss(x, torch.from_numpy(s["loss_target"]), torch.from_numpy(s["loss_scenes"]))
+    assert val.dtype == torch.float64 and abs(val.item() - float(s["loss_value"])) <= 1e-12 * abs(float(s["loss_value"]))
+    (gr,) = torch.autograd.grad(val, x, create_graph=True)
+    (pen,) = torch.autograd.grad((gr ** 2).sum(), x, retain_graph=True)
+    (hv,) = torch.autograd.grad((gr * torch.from_numpy(s["loss_v"])).sum(), x)
+    for got, key in ((gr.detach(), "loss_grad"), (pen, "loss_penalty_grad"), (hv, "loss_hvp")):
+        ref = s[key]
+        assert np.abs(got.numpy() - ref).max() <= 1e-9 * np.abs(ref).max(), key
