@@ -118,17 +118,29 @@ int main()
         {"full launches alternating on 2 free streams", 1, false, true},
         {"2 halves on ONE stream", -2, false, false},
         {"launch floor: a kernel that exits at once, back to back", 0, false, false},
+        {"hipGraph of 100 launches on one stream", 100, false, false},
     };
     const int rounds = std::getenv("K3_ROUNDS") ? std::atoi(std::getenv("K3_ROUNDS")) : 3;
     for (int round = 0; round < rounds; ++round)
         for (const Mode &m : modes) {
             if (!only.empty() && only.find((char)('0' + (&m - modes))) == std::string::npos) continue;
             double best = 1e30;
+            hipGraphExec_t gexec = nullptr;
+            if (m.parts == 100) {           // mode 7: does a captured graph shorten the gap between dependent launches?
+                hipGraph_t graph;
+                CK(hipStreamBeginCapture(st[0], hipStreamCaptureModeThreadLocal));
+                for (int k = 0; k < 100; ++k) CA(launch(0, 1, 0));
+                CK(hipStreamEndCapture(st[0], &graph));
+                CK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+                CK(hipGraphDestroy(graph));
+            }
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipDeviceSynchronize());
                 const auto t0 = std::chrono::steady_clock::now();
                 for (int i = 0; i < steps; ++i) {
-                    if (m.parts == 0) {         // svbrdf_scale_inplace with scale 1: one scalar load, s_endpgm
+                    if (m.parts == 100) {
+                        if (i % 100 == 0) CK(hipGraphLaunch(gexec, st[0]));
+                    } else if (m.parts == 0) {         // svbrdf_scale_inplace with scale 1: one scalar load, s_endpgm
                         CA(p_scale(d_grad, d_one, n, st[0]));
                     } else if (m.parts < 0) {
                         for (int p = 0; p < -m.parts; ++p) CA(launch(p, -m.parts, 0));
@@ -149,8 +161,9 @@ int main()
             }
             // the shader clock the chip holds under this mode's loop (K3_CLOCK=1): a one-wave probe kernel spins 3 ms on a
             // stream of its own (s_memtime against the constant 100 MHz s_memrealtime) while the loop keeps running
+            if (gexec) CK(hipGraphExecDestroy(gexec));
             double ghz = 0.0;
-            if (std::getenv("K3_CLOCK") && p_clock && m.parts > 0 && !m.join) {
+            if (std::getenv("K3_CLOCK") && p_clock && m.parts > 0 && m.parts != 100 && !m.join) {
                 unsigned long long *d_probe, h_probe[2] = {0, 0};
                 CK(hipMalloc(&d_probe, 16)); CK(hipMemset(d_probe, 0, 16));
                 CA(p_clock(d_probe, 300000ULL, st[NS - 1]));
