@@ -311,10 +311,16 @@ struct FusedLossBackward : public torch::autograd::Node {
         const at::Tensor sc = scenes_dev.defined()
                                   ? scenes_dev
                                   : at::from_blob(scenes_host.data(), {B, S, 9}, at::TensorOptions().dtype(at::kFloat)).clone();
-        const pybind11::tuple r = g_hooks.loss(in, tg, sc, eps, l1_weight, eps_l1, head, g0, has_in, has_tg);
         torch::autograd::variable_list out(2);
-        if (!r[0].is_none()) out[0] = r[0].cast<at::Tensor>();
-        if (!r[1].is_none()) out[1] = r[1].cast<at::Tensor>();
+        try {
+            const pybind11::tuple r = g_hooks.loss(in, tg, sc, eps, l1_weight, eps_l1, head, g0, has_in, has_tg);
+            if (!r[0].is_none()) out[0] = r[0].cast<at::Tensor>();
+            if (!r[1].is_none()) out[1] = r[1].cast<at::Tensor>();
+        } catch (pybind11::error_already_set &e) {
+            // an autograd worker thread: hand the engine a plain C++ exception; the Python error state dies here, under the GIL
+            const std::string msg = e.what();
+            throw std::runtime_error("fused rendering loss, backward(create_graph=True): " + msg);
+        }
         return out;
     }
 
@@ -528,7 +534,12 @@ struct RenderBackward : public torch::autograd::Node {
             TORCH_CHECK(g_hooks.render && !g_hooks.render.is_none(), "LocalRenderer.render: backward(create_graph=True) needs "
                                                                        "the package's second-order hook");
             const at::Tensor table = at::from_blob(rows.data(), {(int64_t)S, 9}, at::TensorOptions().dtype(at::kFloat)).clone();
-            out[0] = g_hooks.render(m, table, grads[0]).cast<at::Tensor>();
+            try {
+                out[0] = g_hooks.render(m, table, grads[0]).cast<at::Tensor>();
+            } catch (pybind11::error_already_set &e) {
+                const std::string msg = e.what();
+                    throw std::runtime_error("LocalRenderer.render, backward(create_graph=True): " + msg);
+            }
             return out;
         }
         at::AutoDispatchBelowADInplaceOrView below_autograd;

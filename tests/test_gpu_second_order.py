@@ -241,6 +241,28 @@ def test_seeded_sweep_second_order_against_the_eager_oracle(dev, B, H, S, tiled)
     assert not pen[0, 6:9, 0].cpu().numpy().any()
 
 
+def test_an_error_in_the_second_order_hook_reaches_the_caller(dev):
+    """the C++ nodes run on autograd's worker thread: an exception raised by the Python code they call back into must come
+    out of ``torch.autograd.grad`` as an error, with its message"""
+    from svbrdf_estimation_amd import _hostext, losses, renderers
+    ext = _hostext.module()
+    assert ext is not None, "native host extension not built"
+
+    def broken(*args):
+        raise ZeroDivisionError("deliberate failure in the hook")
+    ext.set_second_order_hooks(broken, broken)
+    try:
+        x = (torch.rand(1, 12, 8, 8, device=dev) * 0.5 + 0.25).requires_grad_(True)
+        loss = losses.RenderingLoss(renderers.LocalRenderer())(x, x.detach() * 0.9)
+        with pytest.raises(RuntimeError, match="deliberate failure in the hook"):
+            torch.autograd.grad(loss, x, create_graph=True)
+    finally:
+        ext.set_second_order_hooks(_hostext._loss_second_order, _hostext._render_second_order)
+    loss = losses.RenderingLoss(renderers.LocalRenderer())(x, x.detach() * 0.9)          # and the path still works afterwards
+    (g,) = torch.autograd.grad(loss, x, create_graph=True)
+    assert g.requires_grad and torch.isfinite(g).all()
+
+
 def test_third_order_is_refused_loudly_and_the_abi_checks_its_arguments(dev):
     from svbrdf_estimation_amd import _native, renderers
     R = renderers.LocalRenderer()
