@@ -397,6 +397,9 @@ def main():
         # Nothing has initialised the GPU runtime in this process and nothing will (see launch.py).
         os.environ["SVBRDF_SELF_SPAWNED"] = "1"
         sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    # this pool's host driver only supports dmabuf IPC: RCCL between rank processes needs it (read when the HSA runtime
+    # starts, i.e. at the first GPU call; the self-spawning parent sets it for its children too)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -129,6 +129,9 @@ def run(args):
     import torch.distributed as dist
     miopen_cache = training.use_in_tree_miopen_cache()      # before the first convolution of the process
 
+    # this pool's host driver only supports dmabuf IPC: RCCL between rank processes needs it (read when the HSA runtime
+    # starts, i.e. at the first GPU call; the self-spawning parent sets it for its children too)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
