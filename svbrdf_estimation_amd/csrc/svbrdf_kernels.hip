@@ -5,6 +5,10 @@
 //   K1 render_fwd            LocalRenderer.render                  renderers.py:67-104
 //   K2 render_bwd            the autograd graph of render()        (66 nodes, ~336 ATen calls)
 //   K3 rendering_loss        RenderingLoss.forward + its backward  losses.py:29-52
+//      (+ SVBRDFL1Loss / MixedLoss, losses.py:7-19, 54-63, and the network head, models.py:338-346, folded in)
+//   K4 mix_materials         SvbrdfDataset.mix                     dataset.py:142-160
+//   float64 maps and second order (the reference's op graph is dtype-agnostic and twice differentiable):
+//      k_render_f64 / k_render_f64_jvp, the same shading in double and in dual numbers
 //
 // Build:  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -shared   (csrc/Makefile)
 //
