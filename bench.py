@@ -592,9 +592,18 @@ def main():
         probe_stream = torch.cuda.Stream(dev)
         probe_out = torch.zeros(2, dtype=torch.int64, device=dev)
         torch.cuda.synchronize(dev)
+        # The probe is launched INTO a loop that has been running for >= 12 ms, not on an idle GPU in front of it: the chip
+        # answers the onset of load after an idle period (even the sync above) with a clock sag to 1.75-2.1 GHz that takes
+        # ~5 ms to recover (tools/clock_timeline.py, profiles/r05_clock_timeline.txt).  Rounds 1-4 launched the probe first
+        # and read 2.1-2.2 GHz where the sustained loop holds 2.38-2.40: their cycle counts and issue fractions were 10-13 %
+        # off (the microseconds were right).
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 12e-3:
+            for _ in range(16):
+                step()
         _native.clock_probe(probe_out, ticks=300000, stream=probe_stream)     # 3 ms of the 100 MHz counter
         t_probe = time.perf_counter()
-        while time.perf_counter() - t_probe < 4.5e-3:                         # the bench loop runs beside the probe
+        while time.perf_counter() - t_probe < 4.5e-3:                         # the bench loop keeps running beside the probe
             for _ in range(16):
                 step()
         torch.cuda.synchronize(dev)
@@ -602,7 +611,8 @@ def main():
         if ticks > 0:
             clock_ghz = cyc / ticks * 0.1
             clock_note = ("measured in this run: s_memtime / s_memrealtime of a one-wave probe kernel spinning %.1f ms on its own "
-                          "stream while the bench loop ran" % (ticks * 1e-5))
+                          "stream, launched into the bench loop after it had run for 12 ms (sustained load; a probe launched "
+                          "on an idle GPU in front of the loop reads the 5 ms clock sag at the onset of load instead)" % (ticks * 1e-5))
     except Exception as e:  # pragma: no cover
         clock_note = "probe failed: %r" % (e,)
     if ns:
