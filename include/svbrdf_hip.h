@@ -205,6 +205,14 @@ SVBRDF_API int svbrdf_mix_materials(const float *svbrdf0, const float *svbrdf1, 
  * stream of its own beside the fused loss: the clock the chip holds under that kernel). */
 SVBRDF_API int svbrdf_debug_clock_probe(unsigned long long *out_dev, unsigned long long ticks_100mhz, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * AUXILIARY entry points -- NOT part of the north-star path (BASELINE.json: fp32 maps, first-order training).
+ * The three svbrdf_*_f64 symbols below serve callers who hand the renderer double maps or differentiate through its
+ * backward (gradient checks, notebook-style direct map optimisation); the reference itself never does either.  They are
+ * compiled from a translation unit of their own (csrc/svbrdf_aux_f64.hip), take none of the tuned kernels' paths, are
+ * frozen since ABI version 6, and a replacement library that serves training only may return SVBRDF_ERR_DIMS from them.
+ * --------------------------------------------------------------------------------------------------------------- */
+
 /* float64 maps (ABI version 5).  LocalRenderer.render is dtype-agnostic in the reference (renderers.py:67-104); with double
  * maps it computes in MIXED precision: pixel grid (torch.linspace, :73), camera / light positions and light colour
  * (torch.Tensor(...), :79,:91,:98) are float32, so wo, wi, h, (1-VH)^5 and colour*falloff are the float32 values of the

@@ -18,6 +18,11 @@ SX=${SCHED_ADJOINT_EXTRA:-$SA}
 /opt/rocm/bin/hipcc $F $SM -DSVBRDF_TU=0 -c -o $out/obj_$tag/main.o $src/svbrdf_kernels.hip &
 /opt/rocm/bin/hipcc $F $SA -DSVBRDF_TU=1 -c -o $out/obj_$tag/adj.o $src/svbrdf_kernels.hip &
 /opt/rocm/bin/hipcc $F $SX -DSVBRDF_TU=3 -c -o $out/obj_$tag/adjx.o $src/svbrdf_kernels.hip &
+AUX=""
+if [ -f $src/svbrdf_aux_f64.hip ]; then      # round 5 on: the auxiliary float64 unit is a file of its own
+  /opt/rocm/bin/hipcc $F -c -o $out/obj_$tag/aux.o $src/svbrdf_aux_f64.hip &
+  AUX=$out/obj_$tag/aux.o
+fi
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o $out/libsvbrdf_$tag.so $out/obj_$tag/main.o $out/obj_$tag/adj.o $out/obj_$tag/adjx.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o $out/libsvbrdf_$tag.so $out/obj_$tag/main.o $out/obj_$tag/adj.o $out/obj_$tag/adjx.o $AUX
 echo built $out/libsvbrdf_$tag.so
