@@ -5,54 +5,126 @@ loss itself shards by batch with no collective).  See train.py at the repository
 from . import data, models  # noqa: F401
 
 
-def use_in_tree_miopen_cache():
-    """The image ships no gfx950 MIOpen database, so on a fresh box the U-Net's first steps compile (and, for every new
-    convolution shape, search) their kernels: 35 s at config 2, 5 min at configs[3].  MIOpen keeps what it built in a
-    user cache; when ``svbrdf_estimation_amd/training/miopen_cache/`` exists (kernel binaries + find results written by an
-    earlier run on an MI355X: ``tools/profile_train.sh`` packs them, ``tools/install_miopen_cache.sh`` unpacks them
-    here; tracked since round 4 with a MANIFEST.json of file hashes, versions and provenance, because a tracked test's
-    run time depends on it) and the user has not pointed MIOpen elsewhere, use it.  Purely a
-    compile/search cache: the kernels are the ones a fresh box builds for itself.  Must run before the first
-    convolution of the process.  Returns the directory used, or None."""
-    import os
-    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_cache")
-    if not os.path.isdir(os.path.join(here, "cache")):
-        return None
-    if os.environ.get("MIOPEN_CUSTOM_CACHE_DIR") == os.path.join(here, "cache"):
-        return here                     # a parent process (the test suite) already pointed MIOpen at the in-tree cache
-    if "MIOPEN_CUSTOM_CACHE_DIR" in os.environ or "MIOPEN_USER_DB_PATH" in os.environ:
-        return None
-    os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(here, "cache")
-    if os.path.isdir(os.path.join(here, "db")):
-        os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(here, "db")
-    return here
+_working_copy = {}      # in-tree cache directory -> the writable copy MIOpen was pointed at
 
 
-def miopen_cache_identity(cache_dir):
-    """What a result was produced with: for the in-tree cache (``use_in_tree_miopen_cache`` returned its directory) the
-    sha256 of its MANIFEST.json, whether the files on disk still are the ones the manifest lists (MIOpen appends to the
-    cache when it meets a new shape), and the MIOpen build it was made with; otherwise a statement that MIOpen's own
-    default (or the user's) cache is in use."""
+def _manifest_mismatches(cache_dir):
+    """-> (manifest sha256 | None, {relative path: bytes grown | "missing"}) for the files MANIFEST.json lists"""
     import hashlib
     import json
     import os
-    if not cache_dir:
-        return {"in_tree": False, "note": "the user's / MIOpen's default cache"}
     man = os.path.join(cache_dir, "MANIFEST.json")
     if not os.path.exists(man):
-        return {"in_tree": True, "manifest_sha256": None, "note": "in-tree cache without a MANIFEST.json (installed by hand)"}
+        return None, {}
     with open(man, "rb") as f:
         raw = f.read()
     spec = json.loads(raw.decode())
-    changed = {}            # file -> bytes it grew by since the manifest (MIOpen appends find results and kernels), or "missing"
+    changed = {}
     for rel, want in spec.get("files", {}).items():
-        path = os.path.join(cache_dir, rel)
         try:
-            with open(path, "rb") as f:
+            with open(os.path.join(cache_dir, rel), "rb") as f:
                 data = f.read()
             if hashlib.sha256(data).hexdigest() != want["sha256"]:
                 changed[rel] = len(data) - want.get("bytes", 0)
         except OSError:
             changed[rel] = "missing"
-    return {"in_tree": True, "manifest_sha256": hashlib.sha256(raw).hexdigest(), "files_match_manifest": not changed,
-            "files_grown_since_manifest_bytes": changed, "miopen_build": spec.get("miopen_build")}
+    return hashlib.sha256(raw).hexdigest(), changed
+
+
+def use_in_tree_miopen_cache(source=None, home=None):
+    """The image ships no gfx950 MIOpen database, so on a fresh box the U-Net's first steps compile (and, for every new
+    convolution shape, search) their kernels: 35 s at config 2, 5 min at configs[3].  MIOpen keeps what it built in a
+    user cache; ``svbrdf_estimation_amd/training/miopen_cache/`` holds one (kernel binaries + find results written by an
+    earlier run on an MI355X, tracked with a MANIFEST.json of file hashes, versions and provenance, because a tracked
+    test's run time depends on it).  MIOpen APPENDS to its user cache whenever it meets a new shape, so it is never
+    pointed at the tracked files themselves (round 4 did, and every GPU test run dirtied the work tree; a read-only
+    install would fail; ranks wrote one sqlite file concurrently).  Instead:
+
+      * the tracked files are checked against MANIFEST.json; a cache whose files no longer match is REFUSED (warning,
+        MIOpen's own default cache is used): nobody runs an unreviewable binary blob that differs from the recorded one;
+      * they are copied once to a writable per-user directory, ``<home>/miopen-<manifest sha256[:16]>/r<LOCAL_RANK>``
+        (home: $SVBRDF_MIOPEN_CACHE_HOME, else ~/.cache/svbrdf_amd, else the system temp directory; one copy per local
+        rank, so ranks never share a database file), and MIOPEN_CUSTOM_CACHE_DIR / MIOPEN_USER_DB_PATH point there;
+      * a user who has set either variable keeps their own cache.
+
+    Purely a compile/search cache: the kernels are the ones a fresh box builds for itself.  Must run before the first
+    convolution of the process.  Returns the in-tree directory whose copy is in use, or None."""
+    import os
+    import shutil
+    import tempfile
+    import warnings
+    here = source or os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_cache")
+    if not os.path.isdir(os.path.join(here, "cache")):
+        return None
+    rank_dir = "r%s" % os.environ.get("LOCAL_RANK", "0")
+    if os.environ.get("SVBRDF_MIOPEN_CACHE_SOURCE") == here and os.environ.get("MIOPEN_CUSTOM_CACHE_DIR"):
+        # a parent process (the test suite, a self-spawning launcher) already did this: its copy serves this process too
+        # when it is the same local rank's; another rank takes a copy of its own next to it
+        inherited = os.path.dirname(os.environ["MIOPEN_CUSTOM_CACHE_DIR"])
+        if os.path.basename(inherited) == rank_dir:
+            _working_copy.setdefault(here, inherited)
+            return here
+        home = home or os.path.dirname(os.path.dirname(inherited))
+    elif "MIOPEN_CUSTOM_CACHE_DIR" in os.environ or "MIOPEN_USER_DB_PATH" in os.environ:
+        return None
+    sha, changed = _manifest_mismatches(here)
+    if sha is None or changed:
+        warnings.warn("the in-tree MIOpen cache %s is not what its MANIFEST.json records (%s): not used" % (
+            here, "no manifest" if sha is None else ", ".join(sorted(changed))))
+        return None
+    bases = [home or os.environ.get("SVBRDF_MIOPEN_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache", "svbrdf_amd"),
+             os.path.join(tempfile.gettempdir(), "svbrdf_amd-%d" % os.getuid())]
+    for base in bases:
+        dst = os.path.join(base, "miopen-%s" % sha[:16], rank_dir)
+        try:
+            if not os.path.isdir(os.path.join(dst, "cache")):
+                os.makedirs(os.path.dirname(dst), exist_ok=True)
+                tmp = tempfile.mkdtemp(prefix=rank_dir + ".tmp", dir=os.path.dirname(dst))
+                for sub in ("cache", "db"):
+                    if os.path.isdir(os.path.join(here, sub)):
+                        shutil.copytree(os.path.join(here, sub), os.path.join(tmp, sub))
+                try:
+                    os.rename(tmp, dst)             # atomic: a concurrent starter of the same rank directory wins or loses whole
+                except OSError:
+                    shutil.rmtree(tmp, ignore_errors=True)
+            if not os.access(os.path.join(dst, "cache"), os.W_OK):
+                continue
+        except OSError:
+            continue
+        os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(dst, "cache")
+        if os.path.isdir(os.path.join(dst, "db")):
+            os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(dst, "db")
+        os.environ["SVBRDF_MIOPEN_CACHE_SOURCE"] = here
+        _working_copy[here] = dst
+        return here
+    warnings.warn("no writable directory for a copy of the in-tree MIOpen cache (tried %s): not used" % ", ".join(bases))
+    return None
+
+
+def miopen_cache_identity(cache_dir):
+    """What a result was produced with: for the in-tree cache (``use_in_tree_miopen_cache`` returned its directory) the
+    sha256 of its MANIFEST.json, whether the TRACKED files are the ones the manifest lists (they must be: MIOpen writes to
+    the working copy only), where that copy is and by how much MIOpen has grown it, and the MIOpen build the cache was
+    made with; otherwise a statement that MIOpen's own default (or the user's) cache is in use."""
+    import json
+    import os
+    if not cache_dir:
+        return {"in_tree": False, "note": "the user's / MIOpen's default cache"}
+    sha, changed = _manifest_mismatches(cache_dir)
+    if sha is None:
+        return {"in_tree": True, "manifest_sha256": None, "note": "in-tree cache without a MANIFEST.json (installed by hand)"}
+    with open(os.path.join(cache_dir, "MANIFEST.json")) as f:
+        spec = json.load(f)
+    out = {"in_tree": True, "manifest_sha256": sha, "files_match_manifest": not changed,
+           "files_grown_since_manifest_bytes": changed, "miopen_build": spec.get("miopen_build")}
+    work = _working_copy.get(cache_dir)
+    if work:
+        grown = {}
+        for rel, want in spec.get("files", {}).items():
+            try:
+                grown[rel] = os.path.getsize(os.path.join(work, rel)) - want.get("bytes", 0)
+            except OSError:
+                grown[rel] = "missing"
+        out["working_copy"] = work
+        out["working_copy_grown_bytes"] = {k: v for k, v in grown.items() if v}
+    return out

@@ -111,3 +111,52 @@ def test_in_tree_miopen_cache_is_what_its_manifest_says():
     ident = training.miopen_cache_identity(here)
     assert ident["in_tree"] and ident["files_match_manifest"] and len(ident["manifest_sha256"]) == 64
     assert training.miopen_cache_identity(None) == {"in_tree": False, "note": "the user's / MIOpen's default cache"}
+
+
+def test_miopen_cache_is_used_through_a_writable_copy_and_refused_when_tampered(tmp_path, monkeypatch):
+    """MIOpen appends to its user cache: it must never be pointed at the tracked files (round 4: every GPU test run
+    dirtied the work tree).  The in-tree cache is verified against its manifest, copied to a per-user directory (one per
+    local rank) and used from there; a cache whose files differ from the manifest is refused."""
+    import shutil
+    import warnings
+    from svbrdf_estimation_amd import training
+    here = os.path.join(os.path.dirname(os.path.abspath(training.__file__)), "miopen_cache")
+    for var in ("MIOPEN_CUSTOM_CACHE_DIR", "MIOPEN_USER_DB_PATH", "SVBRDF_MIOPEN_CACHE_SOURCE", "LOCAL_RANK"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(training, "_working_copy", {})
+    home = str(tmp_path / "home")
+    assert training.use_in_tree_miopen_cache(home=home) == here
+    cache_dir = os.environ["MIOPEN_CUSTOM_CACHE_DIR"]
+    assert cache_dir.startswith(home) and not cache_dir.startswith(here) and cache_dir.endswith(os.path.join("r0", "cache"))
+    assert os.environ["MIOPEN_USER_DB_PATH"].startswith(home) and os.environ["SVBRDF_MIOPEN_CACHE_SOURCE"] == here
+    assert sorted(os.listdir(cache_dir)) == sorted(os.listdir(os.path.join(here, "cache")))
+    with open(os.path.join(cache_dir, os.listdir(cache_dir)[0]), "ab") as f:       # MIOpen appends ...
+        f.write(b"x" * 10)
+    ident = training.miopen_cache_identity(here)
+    assert ident["files_match_manifest"] and ident["working_copy"] == os.path.dirname(cache_dir)    # ... the tracked files stay
+    assert list(ident["working_copy_grown_bytes"].values()) == [10]
+    # a child process of this one (same local rank) reuses the copy; another local rank takes its own next to it
+    monkeypatch.setattr(training, "_working_copy", {})
+    assert training.use_in_tree_miopen_cache() == here and os.environ["MIOPEN_CUSTOM_CACHE_DIR"] == cache_dir
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert training.use_in_tree_miopen_cache() == here
+    assert os.environ["MIOPEN_CUSTOM_CACHE_DIR"] == os.path.join(os.path.dirname(os.path.dirname(cache_dir)), "r3", "cache")
+    # the user's own setting wins
+    for var in ("MIOPEN_CUSTOM_CACHE_DIR", "MIOPEN_USER_DB_PATH", "SVBRDF_MIOPEN_CACHE_SOURCE", "LOCAL_RANK"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")
+    assert training.use_in_tree_miopen_cache(home=home) is None and "MIOPEN_CUSTOM_CACHE_DIR" not in os.environ
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    # tampered source: refused, MIOpen left alone
+    src = str(tmp_path / "src")
+    shutil.copytree(here, src)
+    victim = os.path.join(src, "cache", os.listdir(os.path.join(src, "cache"))[0])
+    with open(victim, "r+b") as f:
+        f.seek(100)
+        b = f.read(1)
+        f.seek(100)
+        f.write(bytes([b[0] ^ 1]))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert training.use_in_tree_miopen_cache(source=src, home=home) is None
+    assert w and "not used" in str(w[0].message) and "MIOPEN_CUSTOM_CACHE_DIR" not in os.environ

@@ -39,7 +39,8 @@ done
 cd $R
 # un-profiled bench line (with the CPU baseline) -- never compare profiled and un-profiled timings
 timeout 400 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-timeout 200 python3 tools/k3_sweep.py > $OUT/${TAG}_k3_sweep.txt 2>&1
-timeout 200 python3 tools/k12_bench.py > $OUT/${TAG}_k12_bench.txt 2>&1
+# back-to-back launches through the C ABI, cycles at the clock under load (the GPU suite's speed guard, as a script)
+PERF_GUARD_REPEATS=2 timeout 200 python3 tests/test_gpu_perf_guard.py > $OUT/${TAG}_perf_guard.txt 2>&1 && cp $OUT/perf_guard.json $OUT/${TAG}_perf_guard.json
+timeout 60 python3 tools/clock_timeline.py > $OUT/${TAG}_clock_timeline.txt 2>&1
 [ -x tools/_build/valu_rate ] && timeout 100 tools/_build/valu_rate > $OUT/${TAG}_valu_rate.txt 2>&1
 tail -c 600 $OUT/${TAG}_bench.json

@@ -8,7 +8,11 @@ os.environ.setdefault("SVBRDF_NO_HOST_EXT", "1")
 import numpy as np, torch
 from svbrdf_estimation_amd import _native, environment
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from k3_sweep import maps
+from bench import synthetic_maps
+
+
+def maps(B, H, gen, tied=True):
+    return synthetic_maps(gen, B, H, tied=tied)
 
 dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(1)

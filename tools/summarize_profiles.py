@@ -117,7 +117,7 @@ if cases:
                        "lane streaming reads, validated on K3's dword reads in round 2; the 8 B per lane reads of K2 are "
                        "uncalibrated).  Working sets beyond the 256 MiB Infinity Cache (tools/kernel_cases.py).",
                "cases": cases}, open(os.path.join(P, "%s_kernel_cases.json" % tag), "w"), indent=1, sort_keys=True)
-for name in ("k3_sweep.txt", "k12_bench.txt", "valu_rate.txt"):
+for name in ("perf_guard.json", "clock_timeline.txt", "valu_rate.txt"):
     src = os.path.join(G, "%s_%s" % (tag, name))
     if os.path.exists(src):
         keep = [l for l in open(src) if "amdgpu.ids" not in l]

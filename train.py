@@ -73,7 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--workers", type=int, default=-1,
                     help="DataLoader worker processes per rank; -1 = from the host: (cpus / ranks on this node) - 1, at "
                          "least 2, at most 16 -- the tiled-PNG reader delivers ~45-60 samples/s per worker "
-                         "(tools/loader_rate.py), a training step consumes hundreds per GPU")
+                         "(profiles/r03_loader_rate.json), a training step consumes hundreds per GPU")
     ap.add_argument("--float-transport", action="store_true",
                     help="tiled-PNG samples: decode to float32 in the DataLoader workers (the reference's way) instead of "
                          "shipping the cropped 8-bit pixels and decoding them on the device with lookup tables (same bits, a "
