@@ -428,6 +428,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # is this device the GPU the rank's CPUs were chosen for?  (PCI address from sysfs against the runtime's; undone if not)
+    placement = launch.crosscheck_placement(placement, local_rank, host_cpus)
     dist = None
     nccl = args.backend == "nccl"
     if world > 1 or args.force_dist:
@@ -563,12 +565,13 @@ def main():
                     "patches_per_s": [B * args.steps / float(e[0]) for e in every],
                     "last_loss": [float(e[1]) for e in every], "scene_seed": [int(e[2]) for e in every],
                     "cpus": [p["cpus"] for p in places], "numa_node": [p["numa_node"] for p in places],
-                    "cpu_binding": [p["source"] for p in places]}
+                    "cpu_binding": [p["source"] for p in places], "pci_crosscheck": [p.get("pci_crosscheck") for p in places]}
     else:
         mean_loss = last.item()
         per_rank = {"elapsed_s": [elapsed], "ms_per_step": [1e3 * elapsed / args.steps],
                     "patches_per_s": [B * args.steps / elapsed], "cpus": [placement["cpus"]],
-                    "numa_node": [placement["numa_node"]], "cpu_binding": [placement["source"]]}
+                    "numa_node": [placement["numa_node"]], "cpu_binding": [placement["source"]],
+                    "pci_crosscheck": [placement.get("pci_crosscheck")]}
 
     if not sample_in_region:                # untimed: the per-launch event samples a short timed region does not carry
         _native.set_launch_hook(hook)

@@ -160,12 +160,18 @@ def _visible_indices(value, n):
     return out
 
 
-def gpu_render_minors(sysfs="/sys", environ=None):
+def gpu_render_minors(sysfs="/sys", environ=None, dev="default"):
     """DRM render minors of the GPUs in the order the HIP runtime numbers them, or None.  KFD topology nodes with
-    simd_count > 0 that this process may read (a device cgroup hides the others, as it hides them from the runtime),
-    in node order = ROCr's agent order; ROCR_VISIBLE_DEVICES then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES select
-    and reorder by index."""
+    simd_count > 0 whose render node this process may OPEN -- sysfs lists every GPU of the host even inside a container
+    that was given only some /dev/dri/renderD* (docker --device without a device cgroup on sysfs), while ROCr enumerates
+    only the accessible ones: counting the others would shift every HIP index to a neighbour's render minor and pin the
+    rank to the wrong NUMA node -- in node order = ROCr's agent order; ROCR_VISIBLE_DEVICES then HIP_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES select and reorder by index.  `dev`: the /dev directory to check the render nodes in ("default":
+    /dev for the real sysfs, no check for a test tree; None: no check).  Anything unreadable or malformed -> None (the
+    rank is left unbound), never an exception."""
     environ = os.environ if environ is None else environ
+    if dev == "default":
+        dev = "/dev" if sysfs == "/sys" else None
     base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
     try:
         names = sorted((n for n in os.listdir(base) if n.isdigit()), key=int)
@@ -177,9 +183,17 @@ def gpu_render_minors(sysfs="/sys", environ=None):
             props = dict(line.split(None, 1) for line in _read(os.path.join(base, n, "properties")).splitlines() if " " in line)
         except OSError:
             continue
-        if int(props.get("simd_count", "0")) > 0:
-            minors.append(int(props.get("drm_render_minor", "-1")))
-            _PCI_OF_MINOR[minors[-1]] = (int(props.get("domain", "0")), int(props.get("location_id", "0")))
+        try:
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+            pci = (int(props.get("domain", "0")), int(props.get("location_id", "0")))
+        except ValueError:
+            return None                      # a properties file this code does not understand: bind nothing
+        if dev is not None and not os.access(os.path.join(dev, "dri", "renderD%d" % minor), os.R_OK | os.W_OK):
+            continue                         # not ours to open: the runtime does not enumerate it either
+        minors.append(minor)
+        _PCI_OF_MINOR[minor] = pci
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES" if "HIP_VISIBLE_DEVICES" in environ else "CUDA_VISIBLE_DEVICES"):
         idx = _visible_indices(environ.get(var), len(minors))
         if idx is None:
@@ -207,6 +221,14 @@ def _numa_node_of_minor(minor, sysfs):
         if node >= 0:
             return node
     return None
+
+
+def pci_address_of_minor(minor):
+    """"dddd:bb:dd.f" of a render minor seen by gpu_render_minors (KFD domain / location_id), or None"""
+    if minor not in _PCI_OF_MINOR:
+        return None
+    domain, loc = _PCI_OF_MINOR[minor]
+    return "%04x:%02x:%02x.%d" % (domain, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
 
 
 def _cores(cpus, sysfs):
@@ -259,7 +281,38 @@ def rank_cpu_placement(local_rank, local_world, share_device=False, sysfs="/sys"
     else:                                                                  # more ranks than cores: share the node
         cpus = sorted(usable)
     return {"cpus": cpus, "numa_node": mine, "render_minor": minors[device_of(local_rank)], "ranks_on_node": n,
+            "pci": pci_address_of_minor(minors[device_of(local_rank)]),
             "source": "sysfs: renderD%d -> numa node %d, core slice %d of %d" % (minors[device_of(local_rank)], mine, k + 1, n)}
+
+
+def crosscheck_placement(placement, device_index, restore_cpus=None):
+    """After torch.cuda.set_device: is the GPU the runtime gave this rank the one its CPUs were chosen for?  Compares the
+    PCI address recorded from sysfs (placement["pci"]) with torch.cuda.get_device_properties(device_index); on a mismatch
+    the binding is undone (affinity back to `restore_cpus`) rather than kept on another GPU's socket.  Records the verdict
+    in placement["pci_crosscheck"] ("match", "mismatch: ...", or why it could not be made) and returns the placement."""
+    want = placement.get("pci")
+    if not placement.get("bound") or want is None:
+        placement["pci_crosscheck"] = "not applicable: unbound" if not placement.get("bound") else "not applicable: no PCI address in sysfs"
+        return placement
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device_index)
+        got = "%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except Exception as e:          # a torch build without the PCI fields: nothing to compare
+        placement["pci_crosscheck"] = "not checked: %r" % (e,)
+        return placement
+    if want.rsplit(".", 1)[0] == got:
+        placement["pci_crosscheck"] = "match"
+        return placement
+    placement["pci_crosscheck"] = "mismatch: sysfs says %s, the runtime's device %d is %s -- binding undone" % (want, device_index, got)
+    if restore_cpus:
+        try:
+            os.sched_setaffinity(0, restore_cpus)
+            placement.update(bound=False, cpus=format_cpulist(sorted(restore_cpus)), n_cpus=len(restore_cpus), numa_node=None,
+                             source=placement["source"] + " (undone: PCI mismatch)")
+        except OSError:
+            pass
+    return placement
 
 
 def bind_rank_to_gpu_numa(local_rank, local_world, share_device=False):

@@ -68,7 +68,7 @@ class _FusedRenderingLoss(torch.autograd.Function):
         # over and scales them in place -- no copy, no extra pass; under retain_graph=True they stay with the graph and
         # every backward receives a scaled copy, so repeated backwards work as through the reference's plain-autograd
         # loss (losses.py:29-52), and a second backward without it fails like autograd's own nodes do.
-        keep = torch._C._autograd._get_current_graph_task_keep_graph()
+        keep = _current_backward_keeps_graph()
         if not keep:
             ctx.grads = None
         scale = grad_loss.detach().to(torch.float32).reshape(1)
@@ -76,6 +76,15 @@ class _FusedRenderingLoss(torch.autograd.Function):
         for g in (grad_in, grad_tg):
             outs.append(None if g is None else _native.scale_inplace_(g.clone() if keep else g, scale))
         return outs[0], outs[1], None, None, None, None, None
+
+
+# private autograd accessor, looked up once: a torch build without it falls back to "the graph is kept" -- every backward
+# then receives a scaled COPY of the kernel's buffers (the behaviour before the hand-over existed), never an AttributeError
+_keep_graph_accessor = getattr(getattr(torch._C, "_autograd", None), "_get_current_graph_task_keep_graph", None)
+
+
+def _current_backward_keeps_graph():
+    return True if _keep_graph_accessor is None else bool(_keep_graph_accessor())
 
 
 def composed_loss(input, target, scenes, eps, l1_weight=0.0, eps_l1=0.01, head=False):
@@ -186,7 +195,7 @@ class RenderingLoss(nn.Module):
             return type(r).render is renderers.LocalRenderer.render and "render" not in vars(r)
         return _refcode.is_reference_local_renderer(r)
 
-    def _forward_double(self, input, target, l1_weight):
+    def _forward_double(self, input, target, l1_weight, eps_l1=0.01):
         """float64 maps: the reference's loss (losses.py:29-52) is dtype-agnostic and, with double maps, mixed precision
         (float32 geometry, double shading -- see svbrdf_render_fwd_f64).  Composed here from the float64 renders through
         autograd: S renders per item in one K1 launch, log / L1 by torch in double, the backward through K2.  The slow
@@ -196,11 +205,12 @@ class RenderingLoss(nn.Module):
             raise _native.NativeLibraryError("RenderingLoss needs tensors on a ROCm device (got %s); there is no CPU "
                                              "fallback" % input.device)
         table = self.sample_scene_table(input.shape[0]).to(input.device)
-        return composed_loss(input, target, table, self.epsilon_render, l1_weight)
+        return composed_loss(input, target, table, self.epsilon_render, l1_weight, eps_l1)
 
     def _forward_fused(self, input, target, l1_weight=0.0, eps_l1=0.01, head=False):
-        if not head and input.dtype == torch.float64:
-            return self._forward_double(input, target, l1_weight)
+        if not head and torch.float64 in (input.dtype, target.dtype):
+            # either side double: the reference's torch ops promote, so does this (composed_loss computes in double)
+            return self._forward_double(input, target, l1_weight, eps_l1)
         if head:
             if input.dim() != 4 or target.dim() != 4 or input.shape[1] != 9 or target.shape[1] != 12:
                 raise ValueError("head-fused loss needs input [B,9,H,W] and target [B,12,H,W]")

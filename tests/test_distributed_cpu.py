@@ -189,11 +189,17 @@ def test_train_gpus_n_spawns_n_ranks_cpu(tmp_path):
     """train.py --gpus 2 as one plain process (CPU plumbing configuration: gloo, stock L1 loss)"""
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--gpus", "2", "--device", "cpu", "--loss", "l1",
-                        "--steps", "1", "--warmup", "0", "--batch", "1", "--workers", "0"], env=_clean_env(),
+                        "--steps", "1", "--warmup", "0", "--batch", "1", "--workers", "0", "--ddp-probe"], env=_clean_env(),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == 2
+    # the DDP probe steps after the timed region: a step inside model.no_sync() (forward AND backward: DDP decides at the
+    # forward) must leave the gradients rank-local, a synchronised one equal on both ranks -- the probe checks what it times
+    probe = lines[0]["ddp_backward_probe"]
+    assert probe["samples_each"] == 3 and probe["backward_ms_no_sync"] > 0 and probe["backward_ms_with_allreduce"] > 0
+    assert probe["grad_checksum_spread_over_ranks_synced"] <= 1e-9 < probe["grad_checksum_spread_over_ranks_no_sync"]
+    assert probe["no_sync_left_gradients_rank_local"] is True
 
 
 def test_verify_global_batch_two_ranks_equal_one_cpu(tmp_path):
@@ -325,7 +331,43 @@ def test_rank_cpu_placement_follows_the_gpu_numa_node(tmp_path):
     os.makedirs(os.path.join(root3, "bus/pci/devices/0000:a4:00.0"))
     with open(os.path.join(root3, "bus/pci/devices/0000:a4:00.0/numa_node"), "w") as f:
         f.write("1\n")
-    assert launch.rank_cpu_placement(0, 1, sysfs=root3, environ={}, allowed=allowed)["numa_node"] == 1
+    p3 = launch.rank_cpu_placement(0, 1, sysfs=root3, environ={}, allowed=allowed)
+    assert p3["numa_node"] == 1 and p3["pci"] == "0000:a4:00.0"
+    # a container that was given only SOME /dev/dri/renderD* (sysfs still lists every GPU of the host): only the render
+    # nodes this process may open count -- the runtime enumerates exactly those -- so HIP index 0 is GPU 5 here, not GPU 0
+    fake_dev = tmp_path / "dev"
+    (fake_dev / "dri").mkdir(parents=True)
+    for m in (168, 176):
+        (fake_dev / "dri" / ("renderD%d" % m)).write_text("")
+    assert launch.gpu_render_minors(root, {}, dev=str(fake_dev)) == [168, 176]
+    assert launch.gpu_render_minors(root, {}, dev=None) == [128 + 8 * i for i in range(8)]
+    os.chmod(str(fake_dev / "dri" / "renderD176"), 0o000)
+    if os.geteuid() != 0:                                                      # root opens anything: nothing to test then
+        assert launch.gpu_render_minors(root, {}, dev=str(fake_dev)) == [168]
+    # a properties file this code does not understand leaves the rank unbound instead of raising at start-up
+    root4 = str(tmp_path / "sys4")
+    _fake_sysfs(root4, [0, 1], nodes)
+    with open(os.path.join(root4, "class/kfd/kfd/topology/nodes/2/properties"), "a") as f:
+        f.write("simd_count many\n")
+    assert launch.gpu_render_minors(root4, {}) is None
+    u = launch.rank_cpu_placement(0, 1, sysfs=root4, environ={}, allowed=allowed)
+    assert u["numa_node"] is None and u["source"].startswith("unbound")
+
+
+def test_placement_crosscheck_against_the_runtime_pci_address(monkeypatch):
+    """launch.crosscheck_placement: the PCI address read from sysfs for the rank's GPU against the one the runtime reports
+    for the device the rank got; a mismatch undoes the CPU binding (it would sit on another GPU's socket)"""
+    import types
+    from svbrdf_estimation_amd import launch
+    before = os.sched_getaffinity(0)
+    props = types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0xa4, pci_device_id=0)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: props)
+    ok = launch.crosscheck_placement({"bound": True, "pci": "0000:a4:00.0", "cpus": "0-1", "n_cpus": 2, "numa_node": 1, "source": "sysfs"}, 0, before)
+    assert ok["pci_crosscheck"] == "match" and ok["bound"]
+    bad = launch.crosscheck_placement({"bound": True, "pci": "0000:25:00.0", "cpus": "0-1", "n_cpus": 2, "numa_node": 0, "source": "sysfs"}, 0, before)
+    assert bad["pci_crosscheck"].startswith("mismatch") and not bad["bound"] and bad["numa_node"] is None
+    assert bad["n_cpus"] == len(before) and os.sched_getaffinity(0) == before
+    assert launch.crosscheck_placement({"bound": False, "pci": None}, 0)["pci_crosscheck"].startswith("not applicable")
 
 
 def test_bind_rank_pins_the_process_and_reports_a_cpulist(tmp_path):

@@ -85,6 +85,23 @@ def test_float64_losses_match_the_reference(dev, golden):
     # a float32 target with a double input is promoted, as torch promotes in the reference
     torch.manual_seed(3)
     assert losses.RenderingLoss(renderers.LocalRenderer())(torch.from_numpy(g["loss_input"]).to(dev), tgt.float()).dtype == torch.float64
+    # ... and the other way round: float32 input, double target (this fell into the float32 kernel and raised)
+    torch.manual_seed(3)
+    x32 = torch.from_numpy(g["loss_input"]).float().to(dev).requires_grad_(True)
+    v = losses.RenderingLoss(renderers.LocalRenderer())(x32, tgt)
+    assert v.dtype == torch.float64
+    v.backward()
+    assert x32.grad.dtype == torch.float32 and torch.isfinite(x32.grad).all()
+    # MixedLoss on double maps honours the L1 loss's epsilon like the float32 fused path (it was dropped: always 0.01)
+    vals = []
+    for e in (0.01, 0.05):
+        mixed = losses.MixedLoss(renderers.LocalRenderer())
+        mixed.l1_loss.epsilon_l1 = e
+        mixed.rendering_loss.sample_scene_table = lambda B, _t=torch.from_numpy(g["mixed_scenes"]): _t.clone()
+        vals.append((mixed(torch.from_numpy(g["loss_input"]).to(dev), tgt).item(),
+                     mixed(torch.from_numpy(g["loss_input"]).float().to(dev), tgt.float()).item()))
+    assert abs(vals[0][0] - vals[1][0]) > 1e-4 * abs(vals[0][0])                      # the epsilon matters ...
+    assert all(abs(d - f) <= 2e-5 * abs(d) for d, f in vals), vals                    # ... and both precisions agree on it
 
 
 def test_float64_gradcheck_of_the_analytic_adjoint(dev):

@@ -118,9 +118,28 @@ def test_train_rccl_ddp_world_of_one():
     probe = line["ddp_backward_probe"]
     assert probe["samples_each"] >= 3 and probe["backward_ms_with_allreduce"] > 0 and probe["backward_ms_no_sync"] > 0
     assert len(line["per_rank"]["cpus"]) == 1 and line["per_rank"]["backward_ms"][0]["no_sync"] > 0
+    assert probe["no_sync_left_gradients_rank_local"] is None              # one rank: nothing to compare (two: next test)
     assert line["config"]["miopen_cache"]["in_tree"] in (True, False) and abs(line["per_gpu_value"] - line["value"]) < 1e-9
     print("train.py over RCCL, world 1: backward %.1f ms with the all-reduce, %.1f ms under no_sync; miopen cache %s" % (
         probe["backward_ms_with_allreduce"], probe["backward_ms_no_sync"], line["config"]["miopen_cache"]))
+
+
+def test_train_two_ranks_ddp_probe_checks_what_it_times():
+    """train.py on two ranks sharing the device (gloo carries DDP's all-reduce): the probe steps after the timed region
+    time a step with DDP's all-reduce and a step under model.no_sync() -- and check it: after a no_sync step (forward AND
+    backward inside the context; DDP reads require_backward_grad_sync at the forward) the ranks' gradients differ, after
+    a synchronised step they are equal.  Round 4's probe entered no_sync around the backward only and timed the
+    all-reduce twice."""
+    line, _ = _run("train.py", "--gpus", 2, "--backend", "gloo", "--share-device", "--steps", 2, "--warmup", 1, "--batch", 2,
+                   "--workers", 0, "--loss", "mixed", timeout=1500)
+    probe = line["ddp_backward_probe"]
+    assert line["ranks_seen"] == 2 and probe["samples_each"] == 3
+    assert probe["grad_checksum_spread_over_ranks_synced"] <= 1e-9 < probe["grad_checksum_spread_over_ranks_no_sync"], probe
+    assert probe["no_sync_left_gradients_rank_local"] is True
+    print("train.py, two ranks on one device (gloo): backward %.1f ms with the all-reduce, %.1f ms under no_sync; checksum "
+          "spread over ranks %.1e synced / %.1e no_sync" % (probe["backward_ms_with_allreduce"], probe["backward_ms_no_sync"],
+                                                            probe["grad_checksum_spread_over_ranks_synced"],
+                                                            probe["grad_checksum_spread_over_ranks_no_sync"]))
 
 
 def test_ddp_fused_loss_two_ranks_equal_the_global_batch(tmp_path):

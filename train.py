@@ -114,8 +114,11 @@ def parse_args(argv=None):
                          "items) -- and writes rank 0's gradient after the first backward (DDP-averaged) and the global "
                          "loss to this file")
     ap.add_argument("--no-ddp-probe", action="store_true",
-                    help="skip the eight untimed steps after the timed region that time loss.backward() with and without "
-                         "DDP's all-reduce (multi-rank GPU runs only)")
+                    help="skip the eight untimed steps after the timed region that time a whole step's forward + backward "
+                         "with DDP's all-reduce and under model.no_sync() (multi-rank GPU runs; CPU runs with --ddp-probe)")
+    ap.add_argument("--ddp-probe", action="store_true",
+                    help="run the DDP probe steps on --device cpu too (host clock instead of HIP events): the gloo tests of "
+                         "the probe's control flow")
     ap.add_argument("--phase-times", action="store_true",
                     help="bracket the phases of every timed step (dataloader wait on the host clock; upload + input "
                          "synthesis, network forward, loss, backward, optimizer with HIP events) and report their means: "
@@ -143,6 +146,7 @@ def run(args):
     # first thing in a rank, before any GPU call: pin it (and the DataLoader workers it will fork) to the CPUs next to its
     # GPU, ranks on one socket splitting that socket's cores (launch.py)
     from svbrdf_estimation_amd import launch
+    host_cpus = os.sched_getaffinity(0)
     placement = launch.bind_rank_to_gpu_numa(local_rank, local_world, args.share_device) if on_gpu else \
         {"cpus": launch.format_cpulist(os.sched_getaffinity(0)), "n_cpus": len(os.sched_getaffinity(0)), "numa_node": None,
          "source": "unbound: --device cpu", "bound": False}
@@ -159,6 +163,7 @@ def run(args):
             raise SystemExit("local rank %d but only %d device(s) visible on this node" % (local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+        placement = launch.crosscheck_placement(placement, local_rank, host_cpus)   # PCI address: sysfs vs the runtime
     else:
         if args.loss != "l1":
             raise SystemExit("the rendering loss has no CPU path; --device cpu only supports --loss l1 (plumbing tests)")
@@ -291,14 +296,19 @@ def run(args):
         e.record()
         return e
 
-    # after the timed region, DDP runs only: the same backward WITH the bucketed all-reduce (DDP's hooks launch a bucket's
-    # all-reduce on RCCL's stream as soon as its gradients exist, overlapping the rest of the backward) and WITHOUT it
-    # (model.no_sync()), alternating, HIP events around loss.backward() -- what the all-reduce of ~320 MB costs a step
-    # beyond the backward it hides behind.  No optimizer step in these (no_sync gradients are rank-local).
-    probe_steps = 8 if (grouped and on_gpu and not verify and not args.no_ddp_probe) else 0
+    # after the timed region, DDP runs only: the same step WITH the bucketed all-reduce (DDP's hooks launch a bucket's
+    # all-reduce on RCCL's stream as soon as its gradients exist, overlapping the rest of the backward) and WITHOUT it,
+    # alternating, HIP events around loss.backward() -- what the all-reduce of ~320 MB costs a step beyond the backward it
+    # hides behind.  DDP decides whether a backward synchronises when the FORWARD runs (require_backward_grad_sync is read
+    # in DistributedDataParallel.forward), so a no_sync probe step has its forward, its loss and its backward inside
+    # model.no_sync() (round 4 entered it around the backward only and measured the all-reduce twice).  Each probe step
+    # also checks what it claims: a checksum of the first parameter's gradient is gathered from every rank -- equal on all
+    # ranks after a synchronised step, rank-local after a no_sync step.  No optimizer step in these.
+    probe_steps = 8 if (grouped and (on_gpu or args.ddp_probe) and not verify and not args.no_ddp_probe) else 0
     end_timed = total_steps
     total_steps += probe_steps
     probe_ms = {True: [], False: []}
+    probe_sums = {True: [], False: []}          # per probe step: the gradient checksum of every rank
     import contextlib
     losses_seen, t0, elapsed, it = [], None, None, batches()
     for step in range(total_steps):
@@ -344,33 +354,44 @@ def run(args):
             probe = (mark(), None) if step in (1, 3) else None
         if hybrid:
             torch.backends.cudnn.deterministic = forward_flag
-        out = model(net_in)
-        if auto and probe is not None:
-            probe = (probe[0], mark())
-            torch.cuda.synchronize(dev)
-            calib[forward_flag] = probe[0].elapsed_time(probe[1])
-        if hybrid:      # backward always takes MIOpen's immediate-mode choice
-            torch.backends.cudnn.deterministic = False
-        if timing:
-            marks.append(mark())
-        if verify and args.loss != "l1":                                         # the scenes of the lower ranks' items
-            if rank > 0:
-                loss_fn.rendering_loss.sample_scene_table(rank * args.batch)
-        loss = loss_fn(out, svbrdf)
-        if verify and args.loss != "l1":                                         # ... and of the higher ranks' items
-            if rank < world - 1:
-                loss_fn.rendering_loss.sample_scene_table((world - 1 - rank) * args.batch)
-        if timing:
-            marks.append(mark())
-        if probing:
-            bw0 = mark()
-        with (contextlib.nullcontext() if synced else model.no_sync()):
+        with (contextlib.nullcontext() if synced else model.no_sync()):      # forward AND backward: see the probe note above
+            out = model(net_in)
+            if auto and probe is not None:
+                probe = (probe[0], mark())
+                torch.cuda.synchronize(dev)
+                calib[forward_flag] = probe[0].elapsed_time(probe[1])
+            if hybrid:      # backward always takes MIOpen's immediate-mode choice
+                torch.backends.cudnn.deterministic = False
+            if timing:
+                marks.append(mark())
+            if verify and args.loss != "l1":                                         # the scenes of the lower ranks' items
+                if rank > 0:
+                    loss_fn.rendering_loss.sample_scene_table(rank * args.batch)
+            loss = loss_fn(out, svbrdf)
+            if verify and args.loss != "l1":                                         # ... and of the higher ranks' items
+                if rank < world - 1:
+                    loss_fn.rendering_loss.sample_scene_table((world - 1 - rank) * args.batch)
+            if timing:
+                marks.append(mark())
+            if probing:
+                bw0 = mark() if on_gpu else time.perf_counter()
             loss.backward()
         if probing:
-            bw1 = mark()
-            torch.cuda.synchronize(dev)
+            if on_gpu:
+                bw1 = mark()
+                torch.cuda.synchronize(dev)
+                ms = bw0.elapsed_time(bw1)
+            else:
+                ms = 1e3 * (time.perf_counter() - bw0)
+            g0 = next(p.grad for p in net.parameters() if p.grad is not None)
+            mine = g0.detach().double().abs().sum().reshape(1)
+            if on_gpu and not nccl:                      # gloo moves host tensors
+                mine = mine.cpu()
+            every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(every, mine)
             if step - end_timed >= 2:                    # the first pair warms the no_sync path up
-                probe_ms[synced].append(bw0.elapsed_time(bw1))
+                probe_ms[synced].append(ms)
+                probe_sums[synced].append([float(e.item()) for e in every])
             optimizer.zero_grad(set_to_none=True)
             continue
         if verify and step == 0:
@@ -400,14 +421,14 @@ def run(args):
         elapsed = time.perf_counter() - t0
     own_elapsed = elapsed
     per_rank = {"elapsed_s": [own_elapsed], "cpus": [placement["cpus"]], "numa_node": [placement["numa_node"]],
-                "cpu_binding": [placement["source"]]}
+                "cpu_binding": [placement["source"]], "pci_crosscheck": [placement.get("pci_crosscheck")]}
     if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         every = [None] * dist.get_world_size()
         dist.all_gather_object(every, {"elapsed_s": own_elapsed, "cpus": placement["cpus"], "numa_node": placement["numa_node"],
-                                       "cpu_binding": placement["source"],
+                                       "cpu_binding": placement["source"], "pci_crosscheck": placement.get("pci_crosscheck"),
                                        "backward_ms": {("with_allreduce" if k else "no_sync"): (sum(v) / len(v) if v else None)
                                                        for k, v in probe_ms.items()}})
         per_rank = {k: [e[k] for e in every] for k in every[0]}
@@ -435,11 +456,22 @@ def run(args):
         result["untimed_leading_steps"] = calib_steps + args.warmup
     if probe_steps:
         w, n = probe_ms[True], probe_ms[False]
+
+        def spread(sums):       # largest relative difference between the ranks' gradient checksums of one step
+            return max((max(v) - min(v)) / max(abs(max(v)), 1e-300) for v in sums) if sums else None
         result["ddp_backward_probe"] = {
             "backward_ms_with_allreduce": sum(w) / len(w), "backward_ms_no_sync": sum(n) / len(n), "samples_each": len(w),
-            "note": "rank 0, untimed steps after the timed region, HIP events around loss.backward(): DDP's bucketed "
-                    "all-reduce (gradient_as_bucket_view, 25 MB buckets) against model.no_sync(); the difference is what the "
-                    "all-reduce of the U-Net's gradients costs a step beyond the backward it overlaps with"}
+            "grad_checksum_spread_over_ranks_synced": spread(probe_sums[True]),
+            "grad_checksum_spread_over_ranks_no_sync": spread(probe_sums[False]),
+            "no_sync_left_gradients_rank_local": (spread(probe_sums[False]) > 1e-9 and spread(probe_sums[True]) <= 1e-9)
+                                                 if world > 1 else None,
+            "note": "rank 0, untimed steps after the timed region, %s around loss.backward(): DDP's bucketed "
+                    "all-reduce (gradient_as_bucket_view, 25 MB buckets) against a step whose forward and backward both ran "
+                    "inside model.no_sync(); the difference is what the all-reduce of the U-Net's gradients costs a step "
+                    "beyond the backward it overlaps with.  grad_checksum_spread_*: sum |grad| of the first parameter, "
+                    "gathered from every rank per probe step -- 0 after a synchronised step, > 0 after a no_sync step (the "
+                    "ranks hold different shards), which is the evidence that the second figure is a backward WITHOUT the "
+                    "all-reduce (with one rank there is nothing to compare)" % ("HIP events" if on_gpu else "the host clock")}
     if auto:
         result["config"]["conv_forward"] = {"chosen": "reference flags" if forward_flag else "immediate mode",
                                             "calibration_ms": {("reference flags" if k else "immediate mode"): v for k, v in calib.items()}}
