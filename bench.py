@@ -79,6 +79,9 @@ def parse_args():
     ap.add_argument("--plumbing-only", action="store_true",
                     help="multi-rank control flow only (rank launch, rendezvous, barrier, MAX over ranks, one JSON line "
                          "with ranks_seen) without touching a GPU: what the CPU test suite runs with --backend gloo")
+    ap.add_argument("--bringup-timeout", type=float, default=60.0,
+                    help="N > 1: seconds the rendezvous + communicator set-up + first all-reduce may take before the rank "
+                         "prints a diagnosis (backend, devices, HSA_ENABLE_IPC_MODE_LEGACY, ...) and exits with code 3")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     ap.add_argument("--cpu-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--engine-threads", action="store_true",
@@ -360,19 +363,20 @@ def secondary_kernels(dev, H):
 def plumbing_only(args, rank, world, placement):
     """--plumbing-only: everything of the multi-rank protocol except the GPU work (CPU test of the launch path)."""
     import torch.distributed as dist
+    seen = 1
     if world > 1:
+        from svbrdf_estimation_amd import distributed
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo")
+        seen = distributed.init_process_group_checked("gloo", None, args.bringup_timeout)
         dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
     if world > 1:
         dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    seen, places = 1, [placement]
+    places = [placement]
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        seen = dist.get_world_size()
         places = [None] * seen
         dist.all_gather_object(places, placement)
     if rank == 0:
@@ -431,6 +435,7 @@ def main():
     # is this device the GPU the rank's CPUs were chosen for?  (PCI address from sysfs against the runtime's; undone if not)
     placement = launch.crosscheck_placement(placement, local_rank, host_cpus)
     dist = None
+    ranks_seen = 1
     nccl = args.backend == "nccl"
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -439,10 +444,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if nccl:
-            dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm
-        else:
-            dist.init_process_group(backend="gloo")
+        # rendezvous + communicator + ONE one-element all-reduce under a watchdog: a bring-up problem on a node this code has
+        # never seen costs --bringup-timeout seconds and leaves a diagnosis on stderr (exit code 3), not the launcher's limit
+        from svbrdf_estimation_amd import distributed as _d
+        ranks_seen = _d.init_process_group_checked("nccl" if nccl else "gloo", dev, args.bringup_timeout)   # nccl = RCCL on ROCm
 
     def barrier():
         if nccl:
@@ -740,7 +745,7 @@ def main():
                            % two["leg"]) if main_ns == 0 else
                           ("`value` = the timed region with --streams %d: independent steps overlap on the GPU; "
                            "value_single_stream = %s" % (main_ns, one["leg"])),
-            "ranks_seen": dist.get_world_size() if dist is not None else 1,
+            "ranks_seen": ranks_seen,       # summed by the bring-up all-reduce itself, not read from the environment
             "process_group": ("%s (%s), world size %d" % (args.backend, "RCCL" if nccl else "CPU transport, plumbing only",
                                                           dist.get_world_size())) if dist is not None else None,
             "per_rank": per_rank,

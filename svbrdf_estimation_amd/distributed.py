@@ -57,3 +57,114 @@ def global_mean(local_mean):
     t = local_mean.detach().clone().reshape(1)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return (t / dist.get_world_size()).reshape(())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bring-up of the process group, fail-fast.  Until an 8-GPU node has run this code, RCCL with more than one device has
+# executed nowhere: if the first real multi-GPU run cannot rendezvous, cannot build its
+# communicator or hangs in its first collective, it must cost one minute and leave a diagnosis -- not sit in
+# init_process_group's 30-minute default until the driver's limit kills it.
+# ---------------------------------------------------------------------------------------------------------------------
+BRINGUP_EXIT_CODE = 3
+
+
+def bringup_diagnosis(backend, device, phase, waited_s):
+    """what a maintainer needs to see when the process group does not come up (one line per fact, for stderr)"""
+    import os
+    env = os.environ
+    try:
+        n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU runtime on this image
+    except Exception as e:  # pragma: no cover
+        n_dev = "? (%r)" % (e,)
+    return "\n".join([
+        "[bring-up] rank %s of %s: process group did not come up -- stuck in %s for %.0f s" % (
+            env.get("RANK", "?"), env.get("WORLD_SIZE", "?"), phase, waited_s),
+        "[bring-up]   backend                      %s%s" % (backend, " (= RCCL on ROCm)" if backend == "nccl" else ""),
+        "[bring-up]   this rank's device           %s   (LOCAL_RANK=%s, LOCAL_WORLD_SIZE=%s)" % (
+            device, env.get("LOCAL_RANK", "?"), env.get("LOCAL_WORLD_SIZE", "?")),
+        "[bring-up]   devices visible to torch     %s   (ROCR_VISIBLE_DEVICES=%s HIP_VISIBLE_DEVICES=%s CUDA_VISIBLE_DEVICES=%s)" % (
+            n_dev, env.get("ROCR_VISIBLE_DEVICES"), env.get("HIP_VISIBLE_DEVICES"), env.get("CUDA_VISIBLE_DEVICES")),
+        "[bring-up]   HSA_ENABLE_IPC_MODE_LEGACY   %s   (hosts whose driver only does dmabuf IPC need 0: RCCL otherwise fails "
+        "with hipIpcGetMemHandle: invalid argument, or hangs)" % env.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+        "[bring-up]   rendezvous                   %s:%s" % (env.get("MASTER_ADDR"), env.get("MASTER_PORT")),
+        "[bring-up]   next steps: every rank started? (one rank per GPU, WORLD_SIZE of them); NCCL_DEBUG=INFO for RCCL's own "
+        "account; --backend gloo separates a rendezvous problem from an RCCL one",
+    ])
+
+
+class _BringupWatchdog:
+    """Exits the process with BRINGUP_EXIT_CODE and the diagnosis if not cancelled within `timeout_s`.  A Python thread
+    (needs the GIL for a moment: torch's blocking calls release it), backed by faulthandler's C-level timer 15 s later,
+    which needs no GIL, dumps every thread's stack -- showing WHERE it hangs -- and exits."""
+
+    def __init__(self, timeout_s, backend, device):
+        import threading
+        self.timeout_s, self.backend, self.device, self.phase = float(timeout_s), backend, device, "start"
+        self._cancel = threading.Event()
+        self._thread = threading.Thread(target=self._run, name="svbrdf-bringup-watchdog", daemon=True)
+
+    def start(self):
+        import faulthandler
+        import sys
+        self._thread.start()
+        try:
+            faulthandler.dump_traceback_later(self.timeout_s + 15.0, exit=True, file=sys.stderr)
+        except Exception:  # pragma: no cover  (stderr without a file descriptor)
+            pass
+        return self
+
+    def _run(self):
+        import os
+        import sys
+        if self._cancel.wait(self.timeout_s):
+            return
+        try:
+            sys.stderr.write(bringup_diagnosis(self.backend, self.device, self.phase, self.timeout_s) + "\n")
+            sys.stderr.flush()
+        finally:
+            os._exit(BRINGUP_EXIT_CODE)
+
+    def cancel(self):
+        import faulthandler
+        self._cancel.set()
+        try:
+            faulthandler.cancel_dump_traceback_later()
+        except Exception:  # pragma: no cover
+            pass
+
+
+def init_process_group_checked(backend, device=None, timeout_s=60.0):
+    """``dist.init_process_group`` + ONE one-element all-reduce (the first collective is where RCCL builds its
+    communicator, opens its IPC handles and its xGMI rings), under a watchdog: if both have not completed within
+    `timeout_s` seconds, or either raises, the diagnosis goes to stderr and the process exits with BRINGUP_EXIT_CODE
+    (launch.spawn_ranks / torchrun then stop the other ranks).  Returns ``ranks_seen`` = the sum of ones over the group
+    -- counted by the collective itself, not read from the environment.  `device`: this rank's torch.device for
+    backend "nccl" (passed as device_id: eager communicator on that device), ignored for gloo."""
+    import os
+    import sys
+    import torch.distributed as dist
+    nccl = backend == "nccl"
+    wd = _BringupWatchdog(timeout_s, backend, device).start()
+    try:
+        wd.phase = "the rendezvous / communicator set-up (init_process_group)"
+        dist.init_process_group(backend=backend, **({"device_id": device} if nccl else {}))
+        wd.phase = "the first collective (all-reduce of one element)"
+        one = torch.ones(1, dtype=torch.float32, device=device if nccl else "cpu")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        seen = int(round(float(one.item())))            # .item(): the reduction has really finished
+    except BaseException as e:
+        wd.cancel()
+        if isinstance(e, (KeyboardInterrupt, SystemExit)):
+            raise
+        import traceback
+        traceback.print_exc()
+        sys.stderr.write(bringup_diagnosis(backend, device, wd.phase + " -- raised %r" % (e,), 0.0) + "\n")
+        sys.stderr.flush()
+        os._exit(BRINGUP_EXIT_CODE)         # not sys.exit: no destructor of a half-built communicator gets to hang
+    wd.cancel()
+    if seen != dist.get_world_size():
+        sys.stderr.write(bringup_diagnosis(backend, device, "the first collective -- it summed %d ones over a group of %d"
+                                           % (seen, dist.get_world_size()), 0.0) + "\n")
+        sys.stderr.flush()
+        os._exit(BRINGUP_EXIT_CODE)
+    return seen

@@ -162,6 +162,43 @@ def test_bench_under_torch_distributed_run_as_the_driver_launches_it():
     assert len(lines[0]["per_rank"]["cpus"]) == 2
 
 
+def test_bring_up_fails_fast_with_a_diagnosis_when_a_rank_never_arrives():
+    """the first real multi-GPU run must not sit in init_process_group's 30-minute default.
+    Rank 0 of a world of two is started and rank 1 never is (a stalled / crashed peer): within --bringup-timeout seconds
+    rank 0 prints what a maintainer needs (backend, devices, HSA_ENABLE_IPC_MODE_LEGACY, its device, the rendezvous) and
+    exits with code 3 -- both entry points, bench.py and train.py."""
+    import subprocess
+    import time
+    for script, extra in (("bench.py", ["--gpus", "2", "--plumbing-only", "--backend", "gloo"]),
+                          ("train.py", ["--gpus", "2", "--device", "cpu", "--loss", "l1", "--steps", "1", "--workers", "0"])):
+        env = _clean_env()
+        env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        t0 = time.monotonic()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, script)] + extra + ["--bringup-timeout", "4"], env=env,
+                           capture_output=True, text=True, timeout=120)
+        took = time.monotonic() - t0
+        assert r.returncode == 3, (script, r.returncode, r.stderr[-1500:])
+        assert took < 60, took
+        err = r.stderr
+        assert "[bring-up] rank 0 of 2" in err and "init_process_group" in err, err[-1500:]
+        assert "backend                      gloo" in err and "HSA_ENABLE_IPC_MODE_LEGACY   0" in err
+        assert "devices visible to torch" in err and "127.0.0.1:%s" % env["MASTER_PORT"] in err
+        assert not _json_lines(r.stdout)                                    # no result line from a run that never ran
+
+
+def test_bring_up_error_is_a_diagnosis_not_a_bare_traceback():
+    """the other failure mode: the rendezvous raises at once (an address that does not resolve) -> same diagnosis, code 3"""
+    import subprocess
+    env = _clean_env()
+    env.update(RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="no-such-host.invalid",
+               MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only", "--backend", "gloo",
+                        "--bringup-timeout", "20"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    assert "[bring-up] rank 1 of 2" in r.stderr and "no-such-host.invalid:29999" in r.stderr
+
+
 def test_bench_refuses_a_world_that_is_not_gpus():
     """a launcher environment whose WORLD_SIZE contradicts --gpus must be an error, not a silent 1-rank run"""
     import subprocess

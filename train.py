@@ -113,6 +113,9 @@ def parse_args(argv=None):
                          "and ONE scene stream (every rank seeds alike and skips the draws that belong to the other ranks' "
                          "items) -- and writes rank 0's gradient after the first backward (DDP-averaged) and the global "
                          "loss to this file")
+    ap.add_argument("--bringup-timeout", type=float, default=60.0,
+                    help="multi-rank: seconds the rendezvous + communicator set-up + first all-reduce may take before the "
+                         "rank prints a diagnosis and exits with code 3")
     ap.add_argument("--no-ddp-probe", action="store_true",
                     help="skip the eight untimed steps after the timed region that time a whole step's forward + backward "
                          "with DDP's all-reduce and under model.no_sync() (multi-rank GPU runs; CPU runs with --ddp-probe)")
@@ -170,6 +173,7 @@ def run(args):
         if args.mix_materials:
             raise SystemExit("--mix-materials blends on the GPU (kernel K4); there is no CPU path for it")
         dev = torch.device("cpu")
+    ranks_seen = 1
     grouped = world > 1 or args.force_dist
     backend = (args.backend or ("nccl" if on_gpu else "gloo")) if grouped else None
     nccl = backend == "nccl"
@@ -180,7 +184,9 @@ def run(args):
             os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend=backend, **({"device_id": dev} if nccl else {}))
+        # rendezvous + communicator + one all-reduce under a watchdog (distributed.init_process_group_checked): exit code 3
+        # and a diagnosis after --bringup-timeout seconds instead of the launcher's limit
+        ranks_seen = distributed.init_process_group_checked(backend, dev if nccl else None, args.bringup_timeout)
 
     def barrier():
         if nccl:
@@ -442,7 +448,7 @@ def run(args):
     result = {"metric": "end-to-end training patches/s (U-Net + %s loss)" % args.loss,
               "value": world * args.batch * args.steps / elapsed, "unit": "patches/s", "n_gpus": world,
               "per_gpu_value": args.batch * args.steps / elapsed,
-              "ranks_seen": dist.get_world_size() if grouped else 1, "per_rank": per_rank,
+              "ranks_seen": ranks_seen, "per_rank": per_rank,
               "process_group": ("%s, world size %d, DistributedDataParallel" % (backend, dist.get_world_size())) if grouped else None,
               "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps, "warmup": args.warmup,
               "loss_first_quarter": first, "loss_last_quarter": last,
