@@ -79,6 +79,9 @@ def parse_args():
     ap.add_argument("--plumbing-only", action="store_true",
                     help="multi-rank control flow only (rank launch, rendezvous, barrier, MAX over ranks, one JSON line "
                          "with ranks_seen) without touching a GPU: what the CPU test suite runs with --backend gloo")
+    ap.add_argument("--regions", type=int, default=9,
+                    help="short forms (--steps < 256): timed regions of --steps steps each, run back to back; `value` is the "
+                         "median region (at least 9; the 2000-step default form times one region)")
     ap.add_argument("--bringup-timeout", type=float, default=60.0,
                     help="N > 1: seconds the rendezvous + communicator set-up + first all-reduce may take before the rank "
                          "prints a diagnosis (backend, devices, HSA_ENABLE_IPC_MODE_LEGACY, ...) and exits with code 3")
@@ -190,6 +193,40 @@ def cpu_baseline(args, inp, tgt, table):
     except Exception as e:  # pragma: no cover
         res["c_oracle_error"] = repr(e)
     return res
+
+
+def replayed_counters(library, B, H, S, record_path=None):
+    """Hardware-counter figures of the headline kernel (HBM bytes, VALU instructions per launch) are NOT measured in a
+    bench run -- rocprofv3 --pmc needs its own passes (tools/collect_profiles.sh) -- but replayed from
+    profiles/k3_hbm_traffic.json.  A replay is honest only for the very code the counters were taken from: the record
+    carries the sha256 of the kernel's instruction bytes (svbrdf_estimation_amd/_codehash.py) and is replayed only when the
+    kernel inside `library` hashes to it and the shape is the recorded one.
+    -> (hbm bytes per launch | None, what was done and why (str) | None, the record (dict) when replayed else None)"""
+    import hashlib
+    path = record_path or os.path.join(ROOT, "profiles", "k3_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None, None, None
+    try:
+        with open(path, "rb") as f:
+            raw = f.read()
+        tj = json.loads(raw.decode())
+        if not (tj.get("B") == B and tj.get("H") == H and tj.get("S") == S):
+            return None, "NOT replayed: %s holds the shape B=%s H=%s S=%s" % (os.path.basename(path), tj.get("B"), tj.get("H"), tj.get("S")), None
+        from svbrdf_estimation_amd import _codehash
+        try:
+            have = _codehash.k3_headline_hash(library)["sha256"]
+        except Exception as e:
+            have = "unreadable (%r)" % (e,)
+        if not tj.get("kernel_code_sha256") or tj["kernel_code_sha256"] != have:
+            return None, ("NOT replayed: profiles/k3_hbm_traffic.json holds counters of kernel code sha256 %s, the kernel in %s "
+                          "is %s -- re-record them (tools/collect_profiles.sh + summarize_profiles.py)"
+                          % (str(tj.get("kernel_code_sha256"))[:16], os.path.basename(library), have[:16])), None
+        return (tj.get("hbm_bytes_per_launch"),
+                "NOT measured in this run: PMC counters of the same kernel and shape recorded with rocprofv3 --pmc by "
+                "tools/collect_profiles.sh, replayed from profiles/k3_hbm_traffic.json (sha1 %s, build %s, kernel code sha256 "
+                "%s = this library's)" % (hashlib.sha1(raw).hexdigest()[:12], tj.get("git_head", "?"), have[:16]), tj)
+    except Exception as e:
+        return None, "NOT replayed: %r" % (e,), None
 
 
 def secondary_kernels(dev, H):
@@ -527,39 +564,54 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        barrier()
-    torch.cuda.synchronize(dev)
-    # one HIP event pair around the WHOLE timed region, on the stream the kernels are launched on (one stream only: with
-    # N streams there is no single stream that sees every launch): region / launches is the average launch duration
-    # including the ~1 us between back-to-back launches, without the end-of-pipe bubbles of per-launch events
-    region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if not ns else None
-    t0 = time.perf_counter()
-    if region:
-        region[0].record(torch.cuda.current_stream(dev))
-    for i in range(args.steps):
-        if sample_in_region:
-            state["i"] = i
-        last = step()
-    state["i"] = -1
-    if region:
-        region[1].record(torch.cuda.current_stream(dev))
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0      # this rank's K steps are done; the job's time is the MAX over ranks (below)
-    if dist is not None:
-        barrier()                           # closing bracket: every rank has finished before anything else happens
-    torch.cuda.synchronize(dev)
+    # ---- the timed region(s).  One region = EXACTLY --steps steps between barrier + synchronize on both sides, its time the
+    # MAX over ranks.  The default form (2000 steps, 75 ms) times one.  A SHORT form (the driver's --steps 20 is 0.76 ms of
+    # GPU time) times N_REGIONS such regions back to back and reports the MEDIAN region: a single 0.8 ms region swung by
+    # +-6 % between runs on one box in round 4 (197-224 k), SURVEY 8d asks for a median over >= 100 iterations, and nine
+    # regions of 20 steps are 180.  Every region is listed in the JSON line (`timed_regions`).
+    n_regions = 1 if args.steps >= 256 else max(9, args.regions)
+    local_elapsed, region_ms, lasts = [], [], []
+    for r in range(n_regions):
+        if dist is not None:
+            barrier()
+        torch.cuda.synchronize(dev)
+        # one HIP event pair around the WHOLE region, on the stream the kernels are launched on (one stream only: with N
+        # streams there is no single stream that sees every launch): region / launches is the average launch duration
+        # including the ~1 us between back-to-back launches, without the end-of-pipe bubbles of per-launch events
+        region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if not ns else None
+        t0 = time.perf_counter()
+        if region:
+            region[0].record(torch.cuda.current_stream(dev))
+        for i in range(args.steps):
+            if sample_in_region:
+                state["i"] = i
+            last = step()
+        state["i"] = -1
+        if region:
+            region[1].record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        local_elapsed.append(time.perf_counter() - t0)   # this rank's K steps are done; the job's time is the MAX over ranks
+        if dist is not None:
+            barrier()                       # closing bracket: every rank has finished before anything else happens
+        torch.cuda.synchronize(dev)
+        region_ms.append(region[0].elapsed_time(region[1]) / args.steps if region else None)
+        lasts.append(last)
     if ns:
         torch.cuda.set_stream(torch.cuda.default_stream(dev))
     _native.set_launch_hook(None)
     per_rank = None
+    job_elapsed = list(local_elapsed)
     if dist is not None:
         where = dev if nccl else "cpu"
-        mine = torch.tensor([elapsed, float(last.item()), float(distributed.rank_seed(313, rank))], dtype=torch.float64,
-                            device=where)
-        t = mine[:1].clone()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor(local_elapsed, dtype=torch.float64, device=where)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)            # per region: the slowest rank's time
+        job_elapsed = [float(v) for v in t.tolist()]
+    median_region = sorted(range(n_regions), key=lambda k: job_elapsed[k])[n_regions // 2]
+    elapsed, last = job_elapsed[median_region], lasts[median_region]
+    region_ms_per_launch = region_ms[median_region]
+    if dist is not None:
+        mine = torch.tensor([local_elapsed[median_region], float(last.item()), float(distributed.rank_seed(313, rank))],
+                            dtype=torch.float64, device=where)
         mean_loss = distributed.global_mean(last.detach() if nccl else last.detach().cpu()).item()
         every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(every, mine)            # for the record: each rank's own clock, last loss and scene seed
@@ -590,7 +642,6 @@ def main():
             torch.cuda.set_stream(torch.cuda.default_stream(dev))
     kernel_ms = sorted(p[0].elapsed_time(p[1]) for p in ev if p is not None)
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
-    region_ms_per_launch = region[0].elapsed_time(region[1]) / args.steps if region else None
 
     # ---- untimed follow-up phases (same process, same tensors): the shader clock under this load, and the OTHER way of
     # issuing the steps (the timed region ran them on one stream -> now alternating on two, and vice versa)
@@ -699,38 +750,25 @@ def main():
         one_launch_ms = region_ms_per_launch if main_ns == 0 else one["ms_per_step"]
         achieved_one = alg_bytes / (one_launch_ms * 1e-3) / 1e9
         achieved_two = alg_bytes / (two["ms_per_step"] * 1e-3) / 1e9
-        traffic = valu_issue = traffic_source = None
-        tpath = os.path.join(ROOT, "profiles", "k3_hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                import hashlib
-                with open(tpath, "rb") as f:
-                    raw = f.read()
-                tj = json.loads(raw.decode())
-                if tj.get("B") == B and tj.get("H") == H and tj.get("S") == S:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_source = ("NOT measured in this run: PMC counters of the same kernel and shape recorded with "
-                                      "rocprofv3 --pmc by tools/collect_profiles.sh, replayed from profiles/k3_hbm_traffic.json "
-                                      "(sha1 %s, build %s)" % (hashlib.sha1(raw).hexdigest()[:12], tj.get("git_head", "?")))
-                    if tj.get("valu_wave_instr_per_launch") and clock_ghz:
-                        # what actually bounds K3: wave64 VALU instructions issued (PMC SQ_INSTS_VALU of the same
-                        # kernel, profiles/) against the SIMD-32 issue peak of one per 2 cycles per SIMD
-                        # (MI355X_MICROARCH.md), 1024 SIMDs, at the clock the chip holds under the timed region's loop
-                        peak = 1024 * clock_ghz * 1e9 / 2.0
-                        rate = tj["valu_wave_instr_per_launch"] / (share_ms * 1e-3)
-                        valu_issue = {"wave_instr_per_launch": tj["valu_wave_instr_per_launch"],
-                                      "of_which_transcendental": tj.get("trans_wave_instr_per_launch"),
-                                      "instr_count_source": traffic_source,
-                                      "achieved_wave_instr_per_s": rate, "peak_wave_instr_per_s": peak,
-                                      "frac": rate / peak,
-                                      # a transcendental holds the SIMD for 6.5 plain issue slots when several waves share
-                                      # it (profiles/r01_valu_trans.txt: 4 rcp + 28 mul vs 32 mul, 4 waves per SIMD)
-                                      "frac_transcendental_weighted":
-                                          (rate / peak) * (1.0 + 5.5 * tj["trans_wave_instr_per_launch"] / tj["valu_wave_instr_per_launch"])
-                                          if tj.get("trans_wave_instr_per_launch") else None,
-                                      "clock_GHz_under_load": clock_ghz, "clock_source": clock_note}
-            except Exception:
-                traffic = valu_issue = traffic_source = None
+        valu_issue = None
+        traffic, traffic_source, tj = replayed_counters(_native.library_path(), B, H, S)
+        if tj is not None and tj.get("valu_wave_instr_per_launch") and clock_ghz:
+            # what actually bounds K3: wave64 VALU instructions issued (PMC SQ_INSTS_VALU of the same
+            # kernel, profiles/) against the SIMD-32 issue peak of one per 2 cycles per SIMD
+            # (MI355X_MICROARCH.md), 1024 SIMDs, at the clock the chip holds under the timed region's loop
+            peak = 1024 * clock_ghz * 1e9 / 2.0
+            rate = tj["valu_wave_instr_per_launch"] / (share_ms * 1e-3)
+            valu_issue = {"wave_instr_per_launch": tj["valu_wave_instr_per_launch"],
+                          "of_which_transcendental": tj.get("trans_wave_instr_per_launch"),
+                          "instr_count_source": traffic_source,
+                          "achieved_wave_instr_per_s": rate, "peak_wave_instr_per_s": peak,
+                          "frac": rate / peak,
+                          # a transcendental holds the SIMD for 6.5 plain issue slots when several waves share
+                          # it (profiles/r01_valu_trans.txt: 4 rcp + 28 mul vs 32 mul, 4 waves per SIMD)
+                          "frac_transcendental_weighted":
+                              (rate / peak) * (1.0 + 5.5 * tj["trans_wave_instr_per_launch"] / tj["valu_wave_instr_per_launch"])
+                              if tj.get("trans_wave_instr_per_launch") else None,
+                          "clock_GHz_under_load": clock_ghz, "clock_source": clock_note}
         working_set = len(batches) * (2 * 12 + 12) * H * H * B * 4
         out = {
             "metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)",
@@ -740,11 +778,22 @@ def main():
             "valu_issue_frac": valu_issue["frac"] if valu_issue else None,      # what bounds K3 (also in roofline, with its inputs)
             "value_single_stream": world * B / (one["ms_per_step"] * 1e-3),
             "value_two_streams_overlapped": world * B / (two["ms_per_step"] * 1e-3),
-            "value_note": ("`value` = the timed region, every step on ONE stream (what a training loop, serialised by its "
-                           "optimizer, gets); value_two_streams_overlapped = independent steps alternating on two streams, %s"
-                           % two["leg"]) if main_ns == 0 else
-                          ("`value` = the timed region with --streams %d: independent steps overlap on the GPU; "
-                           "value_single_stream = %s" % (main_ns, one["leg"])),
+            "timed_regions": {"count": n_regions, "steps_each": args.steps, "median_index": median_region,
+                              "ms_per_step": [1e3 * e / args.steps for e in job_elapsed],
+                              "value": [world * B * args.steps / e for e in job_elapsed],
+                              "spread_max_minus_min_over_median": (max(job_elapsed) - min(job_elapsed)) / elapsed,
+                              "note": "each region: exactly `steps` steps between barrier + synchronize on both sides, MAX over "
+                                      "ranks; `value`, `ms_per_step` and the roofline are the MEDIAN region's" if n_regions > 1 else
+                                      "one region (the form with >= 256 steps)"},
+            "value_note": (("`value` = the MEDIAN of %d consecutive timed regions of %d steps each (all listed in timed_regions); "
+                            % (n_regions, args.steps)) if n_regions > 1 else "") +
+                          (("`value` = the timed region, every step on ONE stream (what a training loop, serialised by its "
+                            "optimizer, gets); value_two_streams_overlapped = independent steps alternating on two streams, %s"
+                            % two["leg"]) if main_ns == 0 else
+                           ("`value` = the timed region with --streams %d: independent steps overlap on the GPU; "
+                            "value_single_stream = %s" % (main_ns, one["leg"]))) +
+                          "; value_through_autograd_engine = the same step when the loss is a node of a larger graph (a network "
+                          "output: the training case)",
             "ranks_seen": ranks_seen,       # summed by the bring-up all-reduce itself, not read from the environment
             "process_group": ("%s (%s), world size %d" % (args.backend, "RCCL" if nccl else "CPU transport, plumbing only",
                                                           dist.get_world_size())) if dist is not None else None,

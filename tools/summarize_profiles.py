@@ -62,6 +62,16 @@ if k3 and "FETCH_SIZE" in summary[k3] and "WRITE_SIZE" in summary[k3]:
                "B": cfg.get("global_batch"), "H": cfg.get("H"), "S": cfg.get("scenes"), "round": tag,
                "distinct_batches": cfg.get("distinct_batches"), "working_set_MiB": cfg.get("working_set_MiB"),
                "git_head": os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip() or "?"}
+    try:        # what the counters belong to: the kernel's machine code in the library that travelled to the GPU box
+        sys.path.insert(0, ROOT)
+        from svbrdf_estimation_amd import _codehash
+        h = _codehash.k3_headline_hash(os.path.join(ROOT, "svbrdf_estimation_amd", "lib", "libsvbrdf_hip.so"))
+        traffic.update(kernel_code_sha256=h["sha256"], kernel_code_symbol=h["symbol"], kernel_code_bytes=h["bytes"],
+                       kernel_code_note="sha256 of the kernel's instruction bytes in the library the counters were recorded with "
+                                        "(svbrdf_estimation_amd/_codehash.py); bench.py replays them only for that code")
+    except Exception as e:
+        traffic["kernel_code_sha256"] = None
+        traffic["kernel_code_note"] = "not hashed: %r" % (e,)
     for key, counter in (("valu_wave_instr_per_launch", "SQ_INSTS_VALU"), ("trans_wave_instr_per_launch", "SQ_INSTS_VALU_TRANS_F32")):
         if counter in summary[k3]:
             traffic[key] = summary[k3][counter]["mean"]
