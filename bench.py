@@ -646,32 +646,37 @@ def main():
     # ---- untimed follow-up phases (same process, same tensors): the shader clock under this load, and the OTHER way of
     # issuing the steps (the timed region ran them on one stream -> now alternating on two, and vice versa)
     state["i"] = -1
-    clock_ghz, clock_note = None, "not measured"
+    # The clock the chip holds under this kernel is not one number: it moves between 2.0 and 2.4 GHz within milliseconds
+    # (power management), differs by box, and sags to ~1.75 GHz for ~5 ms when load arrives after an idle period
+    # (tools/clock_timeline.py, profiles/r05_clock_timeline*.txt).  Cycles per launch therefore need clock and duration from
+    # the SAME interval: an event A on the loop's stream opens the interval, the probe stream waits for A and then spins the
+    # one-wave probe for ~3 ms, and an event B closes the interval after as many steps as run in that time.  (Rounds 1-4
+    # paired the timed region's duration with a clock read in a later interval: good to +-8 %.)
+    clock_ghz, clock_note, cycle_leg_ms = None, "not measured", None
     try:
         probe_stream = torch.cuda.Stream(dev)
         probe_out = torch.zeros(2, dtype=torch.int64, device=dev)
         torch.cuda.synchronize(dev)
-        # The probe is launched INTO a loop that has been running for >= 12 ms, not on an idle GPU in front of it: the chip
-        # answers the onset of load after an idle period (even the sync above) with a clock sag to 1.75-2.1 GHz that takes
-        # ~5 ms to recover (tools/clock_timeline.py, profiles/r05_clock_timeline.txt).  Rounds 1-4 launched the probe first
-        # and read 2.1-2.2 GHz where the sustained loop holds 2.38-2.40: their cycle counts and issue fractions were 10-13 %
-        # off (the microseconds were right).
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < 12e-3:
-            for _ in range(16):
-                step()
-        _native.clock_probe(probe_out, ticks=300000, stream=probe_stream)     # 3 ms of the 100 MHz counter
-        t_probe = time.perf_counter()
-        while time.perf_counter() - t_probe < 4.5e-3:                         # the bench loop keeps running beside the probe
-            for _ in range(16):
-                step()
+        ms_guess = min(local_elapsed) * 1e3 / args.steps
+        k_leg = int(max(16, min(4096, 3.2 / ms_guess)))        # steps that fill the probe's 3 ms (and a little more)
+        for _ in range(max(64, k_leg)):                         # the loop is running (and its queue is deep) when A is recorded
+            step()
+        ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        loop_stream = torch.cuda.current_stream(dev)
+        ev_a.record(loop_stream)
+        probe_stream.wait_event(ev_a)
+        _native.clock_probe(probe_out, ticks=300000, stream=probe_stream)     # 3 ms of the 100 MHz counter, from A on
+        for _ in range(k_leg):
+            step()
+        ev_b.record(loop_stream if not ns else torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
         cyc, ticks = (int(v) for v in probe_out.tolist())
         if ticks > 0:
             clock_ghz = cyc / ticks * 0.1
+            cycle_leg_ms = ev_a.elapsed_time(ev_b) / k_leg if not ns else None
             clock_note = ("measured in this run: s_memtime / s_memrealtime of a one-wave probe kernel spinning %.1f ms on its own "
-                          "stream, launched into the bench loop after it had run for 12 ms (sustained load; a probe launched "
-                          "on an idle GPU in front of the loop reads the 5 ms clock sag at the onset of load instead)" % (ticks * 1e-5))
+                          "stream beside %d steps of the bench loop, probe and steps opened by the same event (clock and duration "
+                          "of one interval)" % (ticks * 1e-5, k_leg))
     except Exception as e:  # pragma: no cover
         clock_note = "probe failed: %r" % (e,)
     if ns:
@@ -757,7 +762,7 @@ def main():
             # kernel, profiles/) against the SIMD-32 issue peak of one per 2 cycles per SIMD
             # (MI355X_MICROARCH.md), 1024 SIMDs, at the clock the chip holds under the timed region's loop
             peak = 1024 * clock_ghz * 1e9 / 2.0
-            rate = tj["valu_wave_instr_per_launch"] / (share_ms * 1e-3)
+            rate = tj["valu_wave_instr_per_launch"] / ((cycle_leg_ms or share_ms) * 1e-3)   # duration of the clock's interval
             valu_issue = {"wave_instr_per_launch": tj["valu_wave_instr_per_launch"],
                           "of_which_transcendental": tj.get("trans_wave_instr_per_launch"),
                           "instr_count_source": traffic_source,
@@ -838,7 +843,8 @@ def main():
                          "valu_issue_clock_GHz": valu_issue["clock_GHz_under_load"] if valu_issue else None,
                          # boxes (and builds: the chip lowers its clock as the issue stream gets denser) differ in clock by
                          # 5-15 %; launch duration x the clock measured in this run is the box-independent figure
-                         "shader_cycles_per_launch": (share_ms * 1e-3 * clock_ghz * 1e9) if clock_ghz else None,
+                         "shader_cycles_per_launch": ((cycle_leg_ms or share_ms) * 1e-3 * clock_ghz * 1e9) if clock_ghz else None,
+                         "shader_cycles_leg_ms_per_launch": cycle_leg_ms,    # the interval the clock was read in (untimed follow-up leg)
                          "valu_issue_wave_instr_per_launch": valu_issue["wave_instr_per_launch"] if valu_issue else None,
                          "patches_per_s_through_autograd_engine": B / (engine_ms_per_step * 1e-3),
                          "consistent_time_per_launch_le_ms_per_step": bool(share_ms <= ms_per_step * 1.0001),

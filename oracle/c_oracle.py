@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libsvbrdf_oracle.so")
+# SVBRDF_ORACLE_SO: another build of the same source (the -fsanitize=address,undefined build of `make asan`, loaded by
+# tests/test_sanitizers.py into a child interpreter with the ASan runtime preloaded)
+_SO = os.environ.get("SVBRDF_ORACLE_SO") or os.path.join(_HERE, "_build", "libsvbrdf_oracle.so")
 _lib = None
 
 _f32p = ctypes.POINTER(ctypes.c_float)

@@ -16,7 +16,8 @@ from . import _native
 
 NAME = "svbrdf_host_ext"
 BUILD_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "host_ext")
-_SO = os.path.join(BUILD_DIR, NAME + ".so")
+# SVBRDF_HOST_EXT_SO: load another build of the same extension (the AddressSanitizer / UBSan build of tests/test_sanitizers.py)
+_SO = os.environ.get("SVBRDF_HOST_EXT_SO") or os.path.join(BUILD_DIR, NAME + ".so")
 _mod = None
 _tried = False
 
@@ -29,6 +30,32 @@ def build(verbose=False):
     cpp_extension.load(name=NAME, sources=[src], build_directory=BUILD_DIR, extra_cflags=["-O2", "-std=c++17", "-ffp-contract=off"],
                        extra_ldflags=["-ldl"], verbose=verbose)
     return _SO
+
+
+def build_sanitized(build_dir, verbose=False):
+    """the same source under -fsanitize=address,undefined into `build_dir` (CPU test infrastructure: the build is loaded
+    into a child interpreter that has the ASan runtime preloaded, never on a GPU box).  Compiled with the command
+    torch.utils.cpp_extension generates for the product build (lib/host_ext/build.ninja) plus the sanitizer flags, but by
+    a plain compiler call: cpp_extension.load would also dlopen the result into THIS process, which has no ASan runtime."""
+    import subprocess
+    import sysconfig
+    from torch.utils import cpp_extension
+    os.makedirs(build_dir, exist_ok=True)
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "host_ext.cpp")
+    out = os.path.join(build_dir, NAME + ".so")
+    if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    cmd = ["c++", "-DTORCH_EXTENSION_NAME=" + NAME, "-DTORCH_API_INCLUDE_EXTENSION_H"]
+    for inc in cpp_extension.include_paths() + [sysconfig.get_paths()["include"]]:
+        cmd += ["-isystem", inc]
+    cmd += ["-fPIC", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fno-omit-frame-pointer",
+            "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+            "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DHIPBLAS_V2", "-shared", src, "-o", out, "-ldl"]
+    for lib in cpp_extension.library_paths():
+        cmd += ["-L" + lib, "-Wl,-rpath," + lib]
+    cmd += ["-lc10", "-ltorch_cpu", "-ltorch", "-ltorch_python"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return out
 
 
 _disabled = False

@@ -1,0 +1,129 @@
+"""Child program of tests/test_sanitizers.py: runs inside an interpreter that has the AddressSanitizer runtime preloaded
+(LD_PRELOAD=libasan.so) and exercises ONE sanitizer-instrumented native build.  CPU only -- never run on a GPU box.
+
+    python tests/sanitizer_child.py oracle     SVBRDF_ORACLE_SO   = oracle/_build/libsvbrdf_oracle_asan.so
+    python tests/sanitizer_child.py hostext    SVBRDF_HOST_EXT_SO = the -fsanitize build of csrc/host_ext.cpp
+
+Prints "SANITIZER-CHILD-OK <n> checks" at the end; a sanitizer report aborts the process before that (halt_on_error=1,
+-fno-sanitize-recover).
+"""
+import itertools
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def golden_loader():
+    import numpy as np
+    gdir = os.path.join(ROOT, "tests", "golden")
+    return lambda name: np.load(os.path.join(gdir, name))
+
+
+def run_oracle():
+    """every check of tests/test_oracle_golden.py that takes only the `oracle` / `golden` fixtures, parametrisations
+    expanded, against the sanitized oracle -- the golden vectors, the edge cases (odd sizes, one scene, clamps), the
+    argument errors"""
+    import test_oracle_golden as T
+    from oracle import c_oracle
+    assert c_oracle._SO.endswith("_asan.so"), c_oracle._SO
+    golden = golden_loader()
+    n = 0
+    for name in sorted(dir(T)):
+        fn = getattr(T, name)
+        if not (name.startswith("test_") and callable(fn)):
+            continue
+        import inspect
+        params = list(inspect.signature(fn).parameters)
+        if name == "test_eager_restatement_against_the_reference_first_and_second_order":
+            continue                                    # eager torch, not the C oracle
+        marks = [m for m in getattr(fn, "pytestmark", []) if m.name == "parametrize"]
+        axes = [[(m.args[0], v) for v in m.args[1]] for m in marks]
+        for combo in itertools.product(*axes) if axes else [()]:
+            kw = dict(combo)
+            if "oracle" in params:
+                kw["oracle"] = c_oracle
+            if "golden" in params:
+                kw["golden"] = golden
+            missing = [p for p in params if p not in kw]
+            assert not missing, (name, missing)
+            fn(**kw)
+            n += 1
+    return n
+
+
+def run_hostext():
+    """everything of csrc/host_ext.cpp a process without a GPU can reach: binding the C ABI by dlsym (and the error for a
+    library that lacks a symbol), the scene sampler against the reference's per-item draw order and RNG state for every
+    shape class (no random / no specular scenes, fewer and more than 16 normal draws per item: ATen's two code paths) and
+    against the g5 fixture, the argument checks of the three entry points (the 288-row limit of a host scene table sits
+    BEHIND the device check and is reached on a GPU only, like the autograd nodes), fast_backward's refusals, the
+    measurement-event and second-order-hook setters."""
+    import numpy as np
+    import torch
+    from svbrdf_estimation_amd import _hostext, _native, environment as env
+    assert "asan" in _hostext._SO, _hostext._SO
+    ext = _hostext.module()
+    assert ext is not None, "sanitized host extension did not load"
+    n = 0
+    for (B, R, M) in [(8, 3, 6), (2, 11, 21), (5, 0, 4), (3, 2, 0), (3, 1, 7), (3, 1, 8), (1, 3, 6), (16, 3, 6), (32, 3, 6)]:
+        for seed in range(4):
+            torch.manual_seed(seed)
+            a = torch.stack([env.scene_table(R, M) for _ in range(B)])
+            sa = torch.get_rng_state()
+            torch.manual_seed(seed)
+            b = ext.sample_scene_table(B, R, M)
+            assert torch.equal(a, b) and torch.equal(sa, torch.get_rng_state()), (B, R, M, seed)
+            n += 1
+    g = golden_loader()("g5_scene_sampler.npz")
+    for seed in (0, 7, 313):
+        torch.manual_seed(seed)
+        got = ext.sample_scene_table(1, 3, 6)[0].numpy()
+        np.testing.assert_allclose(got, g["seed_%d" % seed], rtol=1e-6, atol=2e-7)
+        n += 1
+    x = torch.zeros(2, 12, 8, 8)
+
+    def raises(fn, text):
+        try:
+            fn()
+        except RuntimeError as e:
+            assert text in str(e), (text, str(e))
+            return 1
+        raise AssertionError("no error: " + text)
+    n += raises(lambda: ext.fused_loss(x, x, 3, 6, 0.1, 0.0, 0.01, 0, False), "ROCm device")
+    n += raises(lambda: ext.fused_loss(x, x[:, :9], 3, 6, 0.1, 0.0, 0.01, 0, False), "[B,12,H,W]")
+    n += raises(lambda: ext.fused_loss(x[:, :9], x, 3, 6, 0.1, 0.1, 0.01, 0, True), "ROCm device")
+    n += raises(lambda: ext.fused_loss(x[:, :, :4], x[:, :, :4], 3, 6, 0.1, 0.0, 0.01, 0, False), "ROCm device")
+    n += raises(lambda: ext.fused_loss_with_scenes(x, x, torch.zeros(2, 200, 9), 0.1, 0.0, 0.01, 0, False), "ROCm device")
+    n += raises(lambda: ext.render_shared_scenes(x, torch.zeros(3, 9), 0), "ROCm device")
+    n += raises(lambda: ext.render_shared_scenes(x[:, :9], torch.zeros(3, 9), 0), "[B,12,H,W]")
+    n += raises(lambda: ext.bind(os.path.join(ROOT, "oracle", "_build", "libsvbrdf_oracle.so")), "does not export")
+    n += raises(lambda: ext.bind("/nonexistent/libsvbrdf_hip.so"), "cannot load")
+    ext.bind(_native.library_path())                        # and back to the real library
+    leaf = torch.zeros(3, requires_grad=True)
+    assert ext.fast_backward((leaf * 2).sum(), leaf, 0) is False and ext.fast_backward(torch.zeros(()), leaf, 0) is False
+    ext.set_timing_events(0, 0)
+    ext.set_second_order_hooks(None, None)
+    ext.set_second_order_hooks(_hostext._loss_second_order, _hostext._render_second_order)
+    return n + 4
+
+
+def run_canary():
+    """proof that the instrumentation is live: hand the sanitized oracle an output buffer that is too small -- ASan must
+    abort the process (tests/test_sanitizers.py expects the report, not the OK line)"""
+    import ctypes
+    import numpy as np
+    from oracle import c_oracle
+    assert c_oracle._SO.endswith("_asan.so"), c_oracle._SO
+    W = 16
+    xrow = np.empty(W - 4, np.float32)                     # four floats short
+    c_oracle.lib().svbrdf_oracle_make_xrow(xrow.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), W)
+    return 1
+
+
+if __name__ == "__main__":
+    count = {"oracle": run_oracle, "hostext": run_hostext, "canary": run_canary}[sys.argv[1]]()
+    print("SANITIZER-CHILD-OK %d checks" % count, flush=True)

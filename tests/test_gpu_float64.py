@@ -94,12 +94,15 @@ def test_float64_losses_match_the_reference(dev, golden):
     assert x32.grad.dtype == torch.float32 and torch.isfinite(x32.grad).all()
     # MixedLoss on double maps honours the L1 loss's epsilon like the float32 fused path (it was dropped: always 0.01)
     vals = []
+    from svbrdf_estimation_amd import _hostext
+    _hostext.set_enabled(False)         # the ctypes host path draws its scenes through sample_scene_table (patched below)
     for e in (0.01, 0.05):
         mixed = losses.MixedLoss(renderers.LocalRenderer())
         mixed.l1_loss.epsilon_l1 = e
         mixed.rendering_loss.sample_scene_table = lambda B, _t=torch.from_numpy(g["mixed_scenes"]): _t.clone()
         vals.append((mixed(torch.from_numpy(g["loss_input"]).to(dev), tgt).item(),
                      mixed(torch.from_numpy(g["loss_input"]).float().to(dev), tgt.float()).item()))
+    _hostext.set_enabled(True)
     assert abs(vals[0][0] - vals[1][0]) > 1e-4 * abs(vals[0][0])                      # the epsilon matters ...
     assert all(abs(d - f) <= 2e-5 * abs(d) for d, f in vals), vals                    # ... and both precisions agree on it
 

@@ -30,7 +30,7 @@ def main():
     for _ in range(40):
         calls[0]()
     torch.cuda.synchronize(dev)
-    for mode in ("idle_start", "busy_start"):
+    for mode in ("idle_start", "busy_start", "sustained"):
         n_probe = 60
         outs = torch.zeros(n_probe, 2, dtype=torch.int64, device=dev)
         if mode == "busy_start":            # the GPU has been under this load for 0.3 s when the series starts
@@ -39,6 +39,11 @@ def main():
                 for k in range(32):
                     calls[k % len(calls)]()
                 torch.cuda.synchronize(dev)
+        elif mode == "sustained":           # 0.6 s of launches with NO synchronisation in between (a training loop's load)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.6:
+                for k in range(32):
+                    calls[k % len(calls)]()
         else:
             time.sleep(0.5)
         e_start, e_k0, e_k1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
