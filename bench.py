@@ -660,7 +660,7 @@ def main():
         torch.cuda.synchronize(dev)
         ms_guess = min(local_elapsed) * 1e3 / args.steps
         k_leg = int(max(16, min(4096, 3.2 / ms_guess)))        # steps that fill the probe's 3 ms (and a little more)
-        for _ in range(max(64, k_leg)):                         # the loop is running (and its queue is deep) when A is recorded
+        for _ in range(max(64, k_leg, int(12.0 / ms_guess))):   # >= 12 ms of load first: past the onset sag, queue deep when A is recorded
             step()
         ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         loop_stream = torch.cuda.current_stream(dev)
