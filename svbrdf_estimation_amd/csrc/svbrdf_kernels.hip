@@ -1373,19 +1373,20 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         // the 24 plane loads (and the scene scalars after them): three memory round trips in series in front of every
         // wave's first geometry, and in the first resident round of a launch each of them queues behind the burst of
         // all the waves' plane loads.  Issued here, in front of the plane loads, they are in flight together with them.
-        // Inline asm because the scheduler otherwise sinks them back to their use; the compiler does not count these two
-        // loads in its s_waitcnt bookkeeping, which is safe only because they are OLDER than every load it tracks (the
-        // counter retires in order, extra older loads make its waits stricter) -- tests/test_isa_guard.py checks that
-        // no plane load is issued before them -- and they are consumed behind an explicit vmcnt(0).
+        // Plain loads followed by a scheduling barrier: the machine scheduler (which otherwise sinks them to their use)
+        // cannot move them across it, and the compiler's own s_waitcnt bookkeeping covers them -- safe by construction.
+        // (Rounds 3-4 issued them with inline asm outside that bookkeeping, correct only while they stayed older than every
+        // tracked load; same instruction order, same loops, eight instructions fewer this way.)  tests/test_isa_guard.py
+        // checks that no plane load is issued before them.
         [[maybe_unused]] float x_early = 0.0f, y_early = 0.0f;
         // (by-value-table kernels only: the device-table variants sit at the register limit and answer two more live
         // values in the prologue with spills between the plane loads)
         const bool early_coords = SVBRDF_K3_EARLY_COORDS && EARLY_COORDS && WITH_GRAD && (W & (W - 1)) == 0;
         if (early_coords) {
             const unsigned p32 = (unsigned)pix, sh = (unsigned)__builtin_ctz((unsigned)W);
-            const float *px = xrow + (p32 & (unsigned)(W - 1)), *py = xrow + (p32 >> sh);
-            asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
-                         : "=&v"(x_early), "=&v"(y_early) : "v"(px), "v"(py) : "memory");
+            x_early = xrow[p32 & (unsigned)(W - 1)];
+            y_early = xrow[p32 >> sh];
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (HEAD) {     // input is the [B,9,H,W] post-tanh generator output
             float e[9];
@@ -1462,7 +1463,6 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         const MapK mi = prepare<WITH_GRAD>(in[0]), mt = prepare<false>(tg[0]);
         float x[1], y;
         if (early_coords) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(x_early), "+v"(y_early) : : "memory");
             x[0] = x_early;
             y = -y_early;
         } else if ((W & (W - 1)) == 0) {
