@@ -1,12 +1,27 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun): bench + rocprofv3 passes for the round's evidence.
-# Usage: gpurun -- 'bash tools/collect_profiles.sh r01'
+# Runs ON THE GPU BOX (via gpurun): the round's evidence -- GPU test suite + allowance ledger, the driver's short bench form
+# twice, training-harness lines, rocprofv3 passes, the un-profiled bench line, the speed guard as a script.  SKIP_SUITE=1: the
+# rocprofv3 / bench part only.
+# Usage: gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r05'
 # Outputs land in gpurun_out/<tag>_*; tools/summarize_profiles.py turns them into profiles/<tag>_*.
 set -u
 TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
+cd $R
+if [ -z "${SKIP_SUITE:-}" ]; then
+  # the GPU test suite with its printed evidence lines, and the allowance ledger of that session
+  python3 -m pytest tests -m gpu -x -q -s 2>&1 | grep -E "^\[datapath\]|^\[perf-guard\]|^rank placement|over RCCL|two ranks on one device|DDP \(2 ranks\)|config 4 end to end|ledger:|passed|failed|Error" > $OUT/${TAG}_gputest.txt
+  tail -3 $OUT/${TAG}_gputest.txt
+  cp $OUT/tolerance_uses.txt $OUT/${TAG}_tolerance_uses.txt 2>/dev/null
+  # the driver's short form, twice on this box (`value` = the median of nine 20-step regions: the two must agree within 2 %)
+  python3 bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_short.json 2> $OUT/${TAG}_bench_short.err
+  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/${TAG}_bench_short2.json 2> $OUT/${TAG}_bench_short2.err
+  # training harness lines: RCCL world of one, and two DDP ranks sharing the device (the self-checking no_sync probe)
+  python3 train.py --gpus 1 --force-dist --steps 10 --warmup 3 --batch 8 > $OUT/${TAG}_train_rccl_world1.json 2>/dev/null
+  python3 train.py --gpus 2 --backend gloo --share-device --steps 10 --warmup 3 --batch 8 > $OUT/${TAG}_train_2ranks_share_device.json 2>/dev/null
+fi
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --no-cpu-baseline --no-secondary"
 # kernel-trace + stats (no counters in these passes): the default command (every step on one stream: the duration of a

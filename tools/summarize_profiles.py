@@ -127,7 +127,13 @@ if cases:
                        "lane streaming reads, validated on K3's dword reads in round 2; the 8 B per lane reads of K2 are "
                        "uncalibrated).  Working sets beyond the 256 MiB Infinity Cache (tools/kernel_cases.py).",
                "cases": cases}, open(os.path.join(P, "%s_kernel_cases.json" % tag), "w"), indent=1, sort_keys=True)
-for name in ("perf_guard.json", "clock_timeline.txt", "valu_rate.txt"):
+for name in ("bench_short.json", "bench_short2.json", "train_rccl_world1.json", "train_2ranks_share_device.json"):
+    src = os.path.join(G, "%s_%s" % (tag, name))
+    if os.path.exists(src):
+        js = [l for l in open(src) if l.startswith("{")]
+        if js:
+            json.dump(json.loads(js[-1]), open(os.path.join(P, "%s_%s" % (tag, name)), "w"), indent=1)
+for name in ("perf_guard.json", "clock_timeline.txt", "valu_rate.txt", "gputest.txt", "tolerance_uses.txt"):
     src = os.path.join(G, "%s_%s" % (tag, name))
     if os.path.exists(src):
         keep = [l for l in open(src) if "amdgpu.ids" not in l]
