@@ -7,7 +7,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = ("r04_bench.json", "r04_bench_short.json")
+LINES = ("r05_bench.json", "r05_bench_short.json", "r04_bench.json", "r04_bench_short.json")
 
 
 @pytest.mark.parametrize("name", LINES)
@@ -36,7 +36,16 @@ def test_committed_bench_line_meets_the_contract(name):
     assert alg <= r["traffic"] <= 1.05 * alg                                 # PMC bytes: no wasted re-reads
     # what bounds this kernel, as scalars: VALU issue fraction, the clock it was priced at, cycles per launch
     assert 0.3 < r["valu_issue_frac"] < 1.0 and 1.0 < r["valu_issue_clock_GHz"] < 2.6
-    assert abs(r["shader_cycles_per_launch"] - r["time_per_launch_ms"] * 1e-3 * r["valu_issue_clock_GHz"] * 1e9) < 1.0
+    # cycles = duration x clock of ONE interval: since round 5 an untimed leg opened by the same event as its clock probe
+    leg_ms = r.get("shader_cycles_leg_ms_per_launch") or r["time_per_launch_ms"]
+    assert abs(r["shader_cycles_per_launch"] - leg_ms * 1e-3 * r["valu_issue_clock_GHz"] * 1e9) < 1.0
+    if name.startswith("r05"):
+        # short forms time nine regions and report the median; the replayed counters are keyed to the kernel's code
+        tr = b["timed_regions"]
+        assert tr["count"] == (9 if b["steps"] < 256 else 1) and len(tr["value"]) == tr["count"]
+        assert abs(sorted(tr["value"])[tr["count"] // 2] - b["value"]) <= 1e-9 * b["value"]
+        assert "kernel code sha256" in r["traffic_source"] and b["per_rank"]["pci_crosscheck"] == ["match"]
+        assert 70e3 < r["shader_cycles_per_launch"] < 93e3                  # the GPU suite's guard, on the bench line
     c = b["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "patches/s" and c["value"] > 0 and 1 <= c["cores"] <= c["all_cores_threads"]
     assert "patches" in c["sample"] and ("all_cores_patches_per_s" in c)
