@@ -714,19 +714,29 @@ def main():
     ns = main_ns
     other_ms = sorted(p[0].elapsed_time(p[1]) for p in ev_other if p is not None)
     other_ms_avg = sum(other_ms) / len(other_ms)
-    # one more untimed leg, one stream: `loss.backward()` through PyTorch's autograd engine instead of the engine-free
+    # two more untimed legs, one stream: `loss.backward()` through PyTorch's autograd engine instead of the engine-free
     # accumulate a LEAF input gets (losses._FusedLossTensor).  A network output -- the training case -- always takes the
-    # engine, so this is the step rate of the loss as a node of a larger graph.
+    # engine, so this is the step rate of the loss as a node of a larger graph.  First as the product does it since round 5
+    # (the engine is handed the extension's cached device-resident 1.0 and the node skips its scale launch: one kernel per
+    # step), then with the engine's own ones-fill kernel and the node's no-op scale launch (rounds 1-4: three kernels).
     saved_ns, ns = ns, 0
     saved_fast, losses._FAST_BACKWARD = losses._FAST_BACKWARD, False
-    for _ in range(64):
-        step()
-    torch.cuda.synchronize(dev)
-    t_engine = time.perf_counter()
-    for _ in range(other_steps):
-        step()
-    torch.cuda.synchronize(dev)
-    engine_ms_per_step = 1e3 * (time.perf_counter() - t_engine) / other_steps
+    engine_steps = max(600, other_steps)
+    engine_ms = {}
+    for unit in (False, True):
+        losses._UNIT_GRADIENT = unit
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < 20e-3:       # past the clock sag that follows the synchronize above (section 4.4)
+            for _ in range(32):
+                step()
+        torch.cuda.synchronize(dev)
+        t_engine = time.perf_counter()
+        for _ in range(engine_steps):
+            step()
+        torch.cuda.synchronize(dev)
+        engine_ms[unit] = 1e3 * (time.perf_counter() - t_engine) / engine_steps
+    losses._UNIT_GRADIENT = True
+    engine_ms_per_step, engine_plain_ms_per_step = engine_ms[True], engine_ms[False]
     losses._FAST_BACKWARD, ns = saved_fast, saved_ns
 
     if rank == 0:
@@ -781,6 +791,7 @@ def main():
             "value": patches / elapsed, "unit": "patches/s", "n_gpus": world,
             "per_gpu_value": patches / elapsed / world,
             "value_through_autograd_engine": world * B / (engine_ms_per_step * 1e-3),
+            "value_through_autograd_engine_with_fill_and_scale_launches": world * B / (engine_plain_ms_per_step * 1e-3),
             "valu_issue_frac": valu_issue["frac"] if valu_issue else None,      # what bounds K3 (also in roofline, with its inputs)
             "value_single_stream": world * B / (one["ms_per_step"] * 1e-3),
             "value_two_streams_overlapped": world * B / (two["ms_per_step"] * 1e-3),
@@ -879,11 +890,15 @@ def main():
                                                    / (FP32_VALU_PEAK_TFLOPS * 1e12),
                          "valu_issue": valu_issue},
             "single_stream_through_autograd_engine": {
-                "patches_per_s": B / (engine_ms_per_step * 1e-3), "ms_per_step": engine_ms_per_step, "steps": other_steps,
-                "note": "per GPU, follow-up leg: the same step with loss.backward() going through PyTorch's autograd engine "
-                        "(ones-fill kernel, graph task, the node's no-op scale launch, AccumulateGrad) -- what the loss costs as "
-                        "a node of a larger graph (a network output); `value` uses the engine-free accumulate that a plain "
-                        "loss.backward() on a LEAF input resolves to (%s)" % ("enabled" if saved_fast else "disabled on this torch version")},
+                "patches_per_s": B / (engine_ms_per_step * 1e-3), "ms_per_step": engine_ms_per_step, "steps": engine_steps,
+                "patches_per_s_with_fill_and_scale_launches": B / (engine_plain_ms_per_step * 1e-3),
+                "note": "per GPU, follow-up legs: the same step with loss.backward() going through PyTorch's autograd engine -- what "
+                        "the loss costs as a node of a larger graph (a network output).  Since round 5 a plain loss.backward() hands "
+                        "the engine the extension's cached device-resident 1.0 and the node, recognising it by address, skips its "
+                        "scale launch: one kernel per step (patches_per_s); with the engine's own ones-fill kernel and the node's "
+                        "no-op scale launch, as in rounds 1-4: three (patches_per_s_with_fill_and_scale_launches).  `value` uses "
+                        "the engine-free accumulate that a plain loss.backward() on a LEAF input resolves to (%s)" % (
+                            "enabled" if saved_fast else "disabled on this torch version")},
             "loss": mean_loss,
             "host_path": "native C++ extension (csrc/host_ext.cpp)" if ext is not None else "python + ctypes",
             "autograd_engine": "multithreaded" if args.engine_threads else "calling thread",

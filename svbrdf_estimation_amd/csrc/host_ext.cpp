@@ -22,6 +22,7 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cmath>
 #include <map>
 #include <mutex>
@@ -267,6 +268,10 @@ struct State {
     at::Tensor workspace, xrow;      // the ones selected for the call in flight (under `mu`)
     at::Tensor host_table;           // [B,S,9] sampler target of the by-value route (consumed inside the call)
     int device = -1;
+    // the device-resident upstream gradient 1.0 that `loss.backward()` is given instead of letting the engine fill a fresh
+    // ones tensor (unit_gradient below); the node recognises it by address and skips its scale launch
+    at::Tensor unit_grad;
+    std::atomic<const void *> unit_ptr{nullptr};
 };
 // Deliberately never destroyed: the state owns device tensors, pinned host slots and events, and a static
 // destructor would release them AFTER the HIP runtime has shut down at interpreter exit (observed: a process that
@@ -346,15 +351,19 @@ struct FusedLossBackward : public torch::autograd::Node {
         // a 25 MB device copy, 7.4 us, per step).
         const bool keep = torch::autograd::get_current_graph_task_keep_graph();
         if (!keep) done = true;
+        // A plain `loss.backward()` arrives here with THE unit gradient (losses._FusedLossTensor.backward hands the engine
+        // the cached device-resident 1.0 of unit_gradient() instead of letting it fill a fresh ones tensor): recognised by
+        // address, it needs no scaling at all -- the step is then ONE kernel launch, as on the engine-free leaf path.
+        const bool unit = g0.is_cuda() && g0.data_ptr() == g_state.unit_ptr.load(std::memory_order_relaxed);
         torch::autograd::variable_list out(2);
         at::AutoDispatchBelowADInplaceOrView below_autograd;
         if (has_in) {
             out[0] = keep ? grad_in.clone() : std::move(grad_in);
-            check(g_abi.scale(out[0].data_ptr<float>(), scale.data_ptr<float>(), (size_t)out[0].numel(), stream), "svbrdf_scale_inplace");
+            if (!unit) check(g_abi.scale(out[0].data_ptr<float>(), scale.data_ptr<float>(), (size_t)out[0].numel(), stream), "svbrdf_scale_inplace");
         }
         if (has_tg) {
             out[1] = keep ? grad_tg.clone() : std::move(grad_tg);
-            check(g_abi.scale(out[1].data_ptr<float>(), scale.data_ptr<float>(), (size_t)out[1].numel(), stream), "svbrdf_scale_inplace");
+            if (!unit) check(g_abi.scale(out[1].data_ptr<float>(), scale.data_ptr<float>(), (size_t)out[1].numel(), stream), "svbrdf_scale_inplace");
         }
         return out;
     }
@@ -649,6 +658,20 @@ bool fast_backward(const at::Tensor &loss, const at::Tensor &input, int64_t curr
     return true;
 }
 
+// The upstream gradient of a plain `loss.backward()`: a 0-dim float32 1.0 on the loss's device, created once per device and
+// never written again.  Handing it to torch.autograd.backward as the explicit gradient saves the engine's fill kernel, and
+// FusedLossBackward::apply recognises it by address and skips its own (no-op) scale launch.
+at::Tensor unit_gradient(const at::Tensor &loss)
+{
+    TORCH_CHECK(loss.is_cuda() && loss.scalar_type() == at::kFloat, "unit_gradient: the loss must be a float32 device tensor");
+    std::lock_guard<std::mutex> lock(g_state.mu);
+    if (!g_state.unit_grad.defined() || g_state.unit_grad.device() != loss.device()) {
+        g_state.unit_grad = at::ones({}, loss.options().requires_grad(false));
+        g_state.unit_ptr.store(g_state.unit_grad.data_ptr(), std::memory_order_relaxed);
+    }
+    return g_state.unit_grad;
+}
+
 // the sampler alone (host tensor) -- used by the bit-exactness tests
 at::Tensor sample_scene_table(int64_t batch, int64_t n_random, int64_t n_specular)
 {
@@ -674,6 +697,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("fused_loss_with_scenes", &fused_loss_with_scenes);
     m.def("sample_scene_table", &sample_scene_table);
     m.def("fast_backward", &fast_backward);
+    m.def("unit_gradient", &unit_gradient);
     m.def("render_shared_scenes", &render_shared_scenes);
     m.def("set_second_order_hooks", [](pybind11::object loss, pybind11::object render) {
         g_hooks.loss = std::move(loss);

@@ -135,23 +135,36 @@ _FAST_BACKWARD = _fast_backward_enabled()
 
 
 class _FusedLossTensor(torch.Tensor):
-    """The 0-dim loss the native host path returns for a LEAF input (a material being optimised directly, the bench
-    loop): an ordinary tensor, attached to the autograd graph as usual, whose ``backward()`` first asks the extension
-    whether the call is exactly "accumulate the gradient the kernel already produced into ``input.grad``" (plain
-    ``loss.backward()``: no explicit gradient, no retain/create graph, no ``inputs=``; leaf without hooks; same
-    stream) and, if so, does just that instead of a trip through the autograd engine (a fill kernel for the implicit
-    ones tensor, a graph task, a no-op scale launch: 19 -> 3 us of host time).  Every other use -- including a
-    second ``backward()``, arithmetic on the loss, ``torch.autograd.grad`` -- goes through autograd unchanged."""
+    """The 0-dim loss the native host path returns when a gradient is wanted: an ordinary tensor, attached to the autograd
+    graph as usual, whose ``backward()`` makes a PLAIN call (no explicit gradient, no create_graph) cheaper in two ways.
+
+    * LEAF input (a material being optimised directly, the bench loop), nothing else needing a gradient: the extension is
+      asked whether the call is exactly "accumulate the gradient the kernel already produced into ``input.grad``" (no
+      retain graph, no ``inputs=``; leaf without hooks; same stream) and, if so, does just that instead of a trip through
+      the autograd engine (19 -> 3 us of host time).
+    * otherwise -- a network output, the training case -- the engine runs, but is handed the extension's cached
+      device-resident 1.0 as the explicit upstream gradient instead of filling a fresh ones tensor, and the loss's autograd
+      node, recognising that tensor by address, skips its (no-op) scale launch: the step stays ONE kernel launch instead of
+      three (fill, K3, scale).  Same values bit for bit: multiplying by 1.0 is what was skipped.
+
+    Every other use -- an explicit gradient, ``create_graph=True``, a second ``backward()``, arithmetic on the loss (which
+    yields a plain tensor), ``torch.autograd.grad`` -- goes through autograd unchanged."""
 
     __torch_function__ = torch._C._disabled_torch_function_impl      # ops on it return plain tensors, no dispatch cost
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         src = self.__dict__.pop("_svbrdf_src", None)
-        if src is not None and _FAST_BACKWARD and gradient is None and not retain_graph and not create_graph and inputs is None:
+        if src is not None and gradient is None and not create_graph:
             inner, leaf, ext = src
-            if ext.fast_backward(inner, leaf, _native._raw_stream(leaf.device)):
-                return None
+            if leaf is not None and _FAST_BACKWARD and not retain_graph and inputs is None:
+                if ext.fast_backward(inner, leaf, _native._raw_stream(leaf.device)):
+                    return None
+            if _UNIT_GRADIENT:
+                gradient = ext.unit_gradient(inner)
         return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs)
+
+
+_UNIT_GRADIENT = True       # tests switch it off to compare against the engine's own ones tensor
 
 
 def _check_shapes(input, target):
@@ -223,9 +236,10 @@ class RenderingLoss(nn.Module):
             loss = ext.fused_loss(input, target, int(self.random_configuration_count),
                                   int(self.specular_configuration_count), float(self.epsilon_render),
                                   float(l1_weight), float(eps_l1), _native._raw_stream(input.device), bool(head))
-            if input.is_leaf and input.requires_grad and not target.requires_grad and torch.is_grad_enabled():
-                out = loss.as_subclass(_FusedLossTensor)       # see _FusedLossTensor: backward() may skip the engine
-                out.__dict__["_svbrdf_src"] = (loss, input, ext)
+            if loss.requires_grad:
+                out = loss.as_subclass(_FusedLossTensor)       # see _FusedLossTensor: a plain backward() is made cheaper
+                leaf_only = input.is_leaf and input.requires_grad and not target.requires_grad
+                out.__dict__["_svbrdf_src"] = (loss, input if leaf_only else None, ext)
                 return out
             return loss
         table = self.sample_scene_table(input.shape[0])

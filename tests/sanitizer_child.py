@@ -100,6 +100,7 @@ def run_hostext():
     n += raises(lambda: ext.fused_loss_with_scenes(x, x, torch.zeros(2, 200, 9), 0.1, 0.0, 0.01, 0, False), "ROCm device")
     n += raises(lambda: ext.render_shared_scenes(x, torch.zeros(3, 9), 0), "ROCm device")
     n += raises(lambda: ext.render_shared_scenes(x[:, :9], torch.zeros(3, 9), 0), "[B,12,H,W]")
+    n += raises(lambda: ext.unit_gradient(torch.zeros(())), "float32 device tensor")
     n += raises(lambda: ext.bind(os.path.join(ROOT, "oracle", "_build", "libsvbrdf_oracle.so")), "does not export")
     n += raises(lambda: ext.bind("/nonexistent/libsvbrdf_hip.so"), "cannot load")
     ext.bind(_native.library_path())                        # and back to the real library

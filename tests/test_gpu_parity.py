@@ -1200,15 +1200,47 @@ def test_leaf_backward_shortcut_equals_the_autograd_engine(dev, golden):
     # a target that needs its gradient too
     tg = d_tg.clone().requires_grad_(True)
     both = run(lambda l, x: l.backward(), tg=tg)
-    assert not isinstance(both[0], losses._FusedLossTensor)
+    assert both[0].__dict__.get("_svbrdf_src") is None                  # consumed by backward(); it named no leaf:
     assert torch.equal(both[1].grad, engine[1].grad) and tg.grad is not None and bool(tg.grad.abs().sum() > 0)
-    # a non-leaf input (the training case: the maps come out of a network) never takes the shortcut
-    w = torch.ones(1, device=dev, requires_grad=True)
-    torch.manual_seed(5)
-    loss = fn(d_in * w, d_tg)
-    assert not isinstance(loss, losses._FusedLossTensor)
-    loss.backward()
-    assert torch.isfinite(w.grad).all()
+    # a non-leaf input (the training case: the maps come out of a network) never takes the engine-free shortcut; its plain
+    # backward() goes through the engine with the extension's cached unit gradient (no fill kernel, no scale launch) and
+    # must give the bits the engine gives with its own ones tensor -- also under retain_graph, and a second time
+    ws = []
+    for mode in ("engine", "unit", "unit_retain"):
+        w = torch.ones(1, device=dev, requires_grad=True)
+        torch.manual_seed(5)
+        loss = fn(d_in * w, d_tg)
+        assert isinstance(loss, losses._FusedLossTensor) and loss.__dict__["_svbrdf_src"][1] is None
+        if mode == "engine":
+            torch.Tensor.backward(loss)
+        elif mode == "unit":
+            loss.backward()
+            with pytest.raises(RuntimeError):
+                loss.backward()                                          # freed graph: autograd says so
+        else:
+            loss.backward(retain_graph=True)
+            first = w.grad.clone()
+            loss.backward()                                              # second pass: the engine's own ones, scaled copy
+            assert torch.equal(w.grad, first * 2.0)
+            w.grad = first
+        torch.cuda.synchronize()
+        ws.append(w.grad.clone())
+    assert torch.isfinite(ws[0]).all() and torch.equal(ws[0], ws[1]) and torch.equal(ws[0], ws[2])
+    # the unit gradient is recognised by ADDRESS: an equal-valued other tensor takes the scaling path, same result
+    x = d_in.clone().requires_grad_(True)
+    other_one = run(lambda l, x: l.backward(torch.ones((), device=dev)), x=x)
+    assert torch.equal(other_one[1].grad, engine[1].grad)
+    ext = _hostext.module()
+    u = ext.unit_gradient(engine[0].detach())
+    assert u.item() == 1.0 and u.data_ptr() == ext.unit_gradient(engine[0].detach()).data_ptr() and not u.requires_grad
+    # switched off, a leaf's plain backward is the engine's (bench.py's reference leg)
+    try:
+        losses._UNIT_GRADIENT, saved_fast = False, losses._FAST_BACKWARD
+        losses._FAST_BACKWARD = False
+        plain = run(lambda l, x: l.backward())
+    finally:
+        losses._UNIT_GRADIENT, losses._FAST_BACKWARD = True, saved_fast
+    assert torch.equal(plain[1].grad, engine[1].grad)
 
 
 # ---------------------------------------------------------------- streams
