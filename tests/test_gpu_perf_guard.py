@@ -7,9 +7,9 @@ turns the GPU suite red instead of silently costing 15 %.
 How one figure is measured (``measure``):
   * the exported symbols are called with raw device pointers (ctypes, argument tuples built once: ~5 us of host time
     per launch, far below every kernel here), on a stream of their own;
-  * the timed launches follow an untimed prefill of half as many on the same stream, so the queue is deep when the
-    region opens and the event pair around it spans the device running launches back to back (checked: the host needs
-    less than 0.8 of the device's time to enqueue them);
+  * the timed launches follow an untimed prefill of as many on the same stream, so the queue is deep when the region
+    opens and the event pair around it spans the device running launches back to back (checked: the host needs less
+    time to enqueue the region's launches than the device to run them);
   * the VALU-bound loss kernel is judged in SHADER CYCLES, not microseconds: boxes of this pool hold 1.94-2.18 GHz
     under this kernel (profiles/r04_k3_clock_ab.txt), a spread wider than any regression worth catching.  A second
     probe, on a second stream, opens with the timed launches (it waits for the region's first event), spins for ~90 %
@@ -101,7 +101,7 @@ class Harness:
         for _ in range(repeats):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize(dev)
-            for k in range(n // 2):                      # untimed prefill: the queue is deep before the region opens
+            for k in range(n):                           # untimed prefill: the queue is deep before the region opens
                 calls[k % len(calls)]()
             e0.record(sa)
             if want_clock:
@@ -109,13 +109,15 @@ class Harness:
                 assert self.probe(self.clk_out.data_ptr(), probe_ticks, _fp(sb.cuda_stream)) == 0
             t_host = time.perf_counter()
             for k in range(n):
-                calls[(n // 2 + k) % len(calls)]()
+                calls[(n + k) % len(calls)]()
             host_ms = 1e3 * (time.perf_counter() - t_host)
             e1.record(sa)
             torch.cuda.synchronize(dev)
             dev_ms = e0.elapsed_time(e1)
-            # the host must stay ahead of the device, or the region holds idle gaps that are not the kernel's
-            assert host_ms < 0.8 * dev_ms, "host-bound: %.2f ms to enqueue %d launches the device ran in %.2f ms" % (host_ms, n, dev_ms)
+            # the host must stay ahead of the device, or the region holds idle gaps that are not the kernel's: with a
+            # prefill as long as the region itself queued in front, it does as long as it enqueues the region's launches
+            # in less time than the device needs to run them (measured: 0.55-0.6 of it for K3 at config 2, 0.02 for K1)
+            assert host_ms < dev_ms, "host-bound: %.2f ms to enqueue %d launches the device ran in %.2f ms" % (host_ms, n, dev_ms)
             us = 1e3 * dev_ms / n
             ghz = None
             if want_clock:
