@@ -304,14 +304,17 @@ def crosscheck_placement(placement, device_index, restore_cpus=None):
     if want.rsplit(".", 1)[0] == got:
         placement["pci_crosscheck"] = "match"
         return placement
-    placement["pci_crosscheck"] = "mismatch: sysfs says %s, the runtime's device %d is %s -- binding undone" % (want, device_index, got)
+    placement["pci_crosscheck"] = "mismatch: sysfs says %s, the runtime's device %d is %s" % (want, device_index, got)
     if restore_cpus:
         try:
             os.sched_setaffinity(0, restore_cpus)
             placement.update(bound=False, cpus=format_cpulist(sorted(restore_cpus)), n_cpus=len(restore_cpus), numa_node=None,
                              source=placement["source"] + " (undone: PCI mismatch)")
-        except OSError:
-            pass
+            placement["pci_crosscheck"] += " -- binding undone"
+        except OSError as e:
+            placement["pci_crosscheck"] += " -- binding kept (sched_setaffinity failed: %s)" % e
+    else:
+        placement["pci_crosscheck"] += " -- binding kept (no CPU set to restore)"
     return placement
 
 
