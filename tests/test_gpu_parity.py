@@ -347,6 +347,58 @@ def test_seeded_sweep_of_shapes_and_map_statistics_against_the_oracle(dev, nativ
     assert cases == 36
 
 
+def test_extreme_shapes_at_the_limits_of_the_abi(dev, native, oracle):
+    """Maximum sizes (SURVEY 8c asks for them): the largest batch a launch takes (65,535 = grid.y; one more is refused),
+    more scenes per item than the kernel-argument block or the LDS stage of the forward-only kernels hold (1,706 scenes is
+    the stage's capacity: exact; 1,707 refused forward-only, fine with the gradient, whose kernel reads the table from
+    memory), and a plane beyond the 32-bit plane addressing of the fused loss (refused before anything is launched)."""
+    from svbrdf_estimation_amd import environment
+    lib = native._load()
+    # ---- B = 65,535 items of 2x2 pixels, one scene each (device table: 65,535 rows), K1 / K2 / K3 against the oracle
+    B, H = 65535, 2
+    inp, tgt = synth.make_maps(7101, B, H), synth.make_maps(7102, B, H)
+    torch.manual_seed(71)
+    one = environment.scene_table(1, 2).numpy()
+    table = np.ascontiguousarray(np.tile(one[None, :1], (B, 1, 1)) + (np.arange(B, dtype=np.float32) % 7)[:, None, None] * np.float32(0.01))
+    d_in, d_tg, d_sc = _t(inp, dev), _t(tgt, dev), _t(table, dev)
+    assert_render_strict(_np(native.render_fwd(d_in, d_sc)), oracle.render_fwd(inp, table), "B=65535 K1")
+    cot = synth.uniform01(7103, (B, 1, 3, H, H)) - np.float32(0.5)
+    assert_grad_close(_np(native.render_bwd(d_in, d_sc, _t(cot, dev))), oracle.render_bwd(inp, table, cot), "B=65535 K2",
+                      f64=oracle.render_bwd(inp, table, cot, f64=True))
+    ref_l, ref_g = oracle.rendering_loss(inp, tgt, table)
+    loss, grad = native.rendering_loss(d_in, d_tg, d_sc)
+    assert_loss_close(loss.item(), ref_l, "B=65535 loss")
+    assert_grad_close(_np(grad), ref_g, "B=65535 loss grad", f64=oracle.rendering_loss(inp, tgt, table, f64=True)[1],
+                      tie_map=oracle.loss_tie_map(inp, tgt, table), max_ties=48)
+    p = d_in.data_ptr()
+    assert lib.svbrdf_render_fwd(p, p, p, p, 65536, 1, 2, 2, None) == -2 and b"65535" in lib.svbrdf_last_error()
+    del d_in, d_tg, d_sc, grad
+    # ---- S = 1,706 / 1,707 scenes for one item of 4x4 pixels
+    H = 4
+    inp, tgt = synth.make_maps(7111, 1, H), synth.make_maps(7112, 1, H)
+    torch.manual_seed(72)
+    big = environment.scene_table(569, 1138).numpy()[None]                # 1,707 rows
+    d_in, d_tg = _t(inp, dev), _t(tgt, dev)
+    for S, forward_only_ok in ((1706, True), (1707, False)):
+        tab = np.ascontiguousarray(big[:, :S])
+        ref_l, ref_g = oracle.rendering_loss(inp, tgt, tab)
+        loss, grad = native.rendering_loss(d_in, d_tg, _t(tab, dev))       # with the gradient: table read from memory
+        assert_loss_close(loss.item(), ref_l, "S=%d loss" % S)
+        assert_grad_close(_np(grad), ref_g, "S=%d loss grad" % S, f64=oracle.rendering_loss(inp, tgt, tab, f64=True)[1],
+                          tie_map=oracle.loss_tie_map(inp, tgt, tab), max_ties=48)
+        if forward_only_ok:                                                # forward only: the table is staged in LDS
+            l2, none = native.rendering_loss(d_in, d_tg, _t(tab, dev), want_grad=False)
+            assert none is None
+            assert_loss_close(l2.item(), ref_l, "S=%d forward-only loss" % S)
+        else:
+            with pytest.raises(native.NativeLibraryError, match="too many scenes"):
+                native.rendering_loss(d_in, d_tg, _t(tab, dev), want_grad=False)
+    # ---- a plane beyond 2^25 pixels: refused by the loss before any launch (nothing is dereferenced)
+    need = lib.svbrdf_rendering_loss_workspace_bytes(1, 1, 8192, 8192)
+    assert lib.svbrdf_rendering_loss_fwd_bwd(p, p, p, p, ctypes.c_float(0.1), p, p, p, need, 1, 1, 8192, 8192, None) == -2
+    assert b"2^25" in lib.svbrdf_last_error()
+
+
 def test_tied_and_untied_roughness_paths_agree_with_oracle(dev, native, oracle):
     """the kernels take a one-lobe fast path when a whole wave has tied roughness channels:
     all-tied, none-tied and a patch where only some rows are tied (both paths in one launch)"""

@@ -5,11 +5,13 @@ the device -- so that a change which keeps the counts but loses the schedule, th
 turns the GPU suite red instead of silently costing 15 %.
 
 How one figure is measured (``measure``):
-  * the exported symbols are called with raw device pointers (ctypes, argument tuples built once: ~5 us of host time
-    per launch, far below every kernel here), on a stream of their own;
+  * the exported symbols are called with raw device pointers FROM C (tests/c_host/launch_loop.c, built with gcc on the
+    spot, takes the entry point as a function pointer: the host side of a launch is the ABI function itself, a few
+    microseconds; issued through Python / ctypes a slow host needs 20-35 us per launch, as long as K3 runs), on a
+    stream of their own;
   * the timed launches follow an untimed prefill of as many on the same stream, so the queue is deep when the region
-    opens and the event pair around it spans the device running launches back to back (checked: the host needs less
-    time to enqueue the region's launches than the device to run them);
+    opens and the events around it span the device running launches back to back (checked: the region is enqueued in
+    four chunks, and at every chunk boundary the device has not yet reached the mark set one chunk earlier);
   * the VALU-bound loss kernel is judged in SHADER CYCLES, not microseconds: boxes of this pool hold 1.94-2.18 GHz
     under this kernel (profiles/r04_k3_clock_ab.txt), a spread wider than any regression worth catching.  A second
     probe, on a second stream, opens with the timed launches (it waits for the region's first event), spins for ~90 %
@@ -71,11 +73,29 @@ def _maps(gen, B, H, tied=True):
     return synthetic_maps(gen, B, H, tied=tied)
 
 
+def _build_launch_loops():
+    """tests/c_host/launch_loop.c -> a temporary shared object (gcc): the launches of a measured region are issued from C"""
+    import subprocess
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix="svbrdf_perf_guard_"), "launch_loop.so")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-o", out,
+                           os.path.join(ROOT, "tests", "c_host", "launch_loop.c")])
+    return ctypes.CDLL(out)
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
 class Harness:
     def __init__(self, dev):
         from svbrdf_estimation_amd import _native
         self.native = _native
         self.lib = _native._load()
+        self.loops = _build_launch_loops()
+        for name in ("perf_loop_loss", "perf_loop_render_fwd", "perf_loop_render_bwd", "perf_loop_mix"):
+            getattr(self.loops, name).restype = ctypes.c_int
         self.dev = dev
         self.sa, self.sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         self.probe = self.lib.svbrdf_debug_clock_probe
@@ -85,39 +105,47 @@ class Harness:
         assert self.probe(self.clk_out.data_ptr(), 1, _fp(self.sb.cuda_stream)) == 0     # first use loads the kernel (~6 ms of
         torch.cuda.synchronize(dev)                                                        # host time): not inside a region
 
-    def measure(self, calls, est_us, want_clock=True, repeats=3):
-        """calls: list of zero-argument callables, each enqueueing ONE launch on stream ``self.sa`` (visited round-robin).
+    def _fn(self, name):
+        """the entry point of the library under test as a plain function pointer for the C loops"""
+        return ctypes.cast(getattr(self.lib, name), ctypes.c_void_p)
+
+    def measure(self, enqueue, est_us, want_clock=True, repeats=3):
+        """enqueue(first, n): enqueues launches first .. first+n-1 on stream ``self.sa`` (from C: tests/c_host/launch_loop.c).
         -> dict(us_per_launch, clock_GHz, cycles_per_launch), best repeat."""
         dev, sa, sb = self.dev, self.sa, self.sb
-        n = int(max(12, min(120, 4000.0 / est_us)))          # ~4 ms of launches
+        n = 4 * int(max(3, min(30, 1000.0 / est_us)))       # ~4 ms of launches, in four chunks
+        q = n // 4
         probe_ticks = int(max(20000, min(600000, 0.9 * n * est_us * 100)))   # ~90 % of the region, in 10 ns ticks
         # settle: clocks and caches in their steady state
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.3:
-            for k in range(32):
-                calls[k % len(calls)]()
+            enqueue(0, 32)
             torch.cuda.synchronize(dev)
         best = None
         for _ in range(repeats):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0 = torch.cuda.Event(enable_timing=True)
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             torch.cuda.synchronize(dev)
-            for k in range(n):                           # untimed prefill: the queue is deep before the region opens
-                calls[k % len(calls)]()
+            enqueue(0, n)                                # untimed prefill: the queue is deep before the region opens
             e0.record(sa)
             if want_clock:
                 sb.wait_event(e0)
                 assert self.probe(self.clk_out.data_ptr(), probe_ticks, _fp(sb.cuda_stream)) == 0
             t_host = time.perf_counter()
-            for k in range(n):
-                calls[(n + k) % len(calls)]()
+            behind = []
+            for c in range(4):
+                enqueue(n + c * q, q)
+                marks[c].record(sa)
+                if c:       # has the device already passed the mark set one chunk ago?  Then it is about to run dry.
+                    behind.append(not marks[c - 1].query())
             host_ms = 1e3 * (time.perf_counter() - t_host)
-            e1.record(sa)
             torch.cuda.synchronize(dev)
-            dev_ms = e0.elapsed_time(e1)
-            # the host must stay ahead of the device, or the region holds idle gaps that are not the kernel's: with a
-            # prefill as long as the region itself queued in front, it does as long as it enqueues the region's launches
-            # in less time than the device needs to run them (measured: 0.55-0.6 of it for K3 at config 2, 0.02 for K1)
-            assert host_ms < dev_ms, "host-bound: %.2f ms to enqueue %d launches the device ran in %.2f ms" % (host_ms, n, dev_ms)
+            dev_ms = e0.elapsed_time(marks[-1])
+            # The region must be the device running launches back to back, whatever the host does: at every chunk
+            # boundary the device still had at least one whole chunk (~1 ms of launches) queued in front of it.  (The
+            # host's enqueue time says nothing: with ~200 launches queued -- 10 KB of kernel arguments each -- the launch
+            # call blocks until the device frees a slot, and the host then reads exactly as slow as the device.)
+            assert all(behind), "the device caught up with the host inside the region: %s (host %.2f ms, device %.2f ms)" % (behind, host_ms, dev_ms)
             us = 1e3 * dev_ms / n
             ghz = None
             if want_clock:
@@ -142,23 +170,20 @@ class Harness:
         nbytes = lib.svbrdf_rendering_loss_workspace_bytes(B, S, H, H)
         ws = torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=dev)
         loss = torch.empty(1, device=dev)
-        st = _fp(self.sa.cuda_stream)
-        fn = lib.svbrdf_mixed_loss_fwd_bwd_host_scenes
-        keep, calls = [table, xr, ws, loss], []
-        for _ in range(sets):
-            a, t = _maps(gen, B, H, tied).to(dev), _maps(gen, B, H, tied).to(dev)
-            g = torch.empty_like(a)
-            keep += [a, t, g]
-            args = (a.data_ptr(), t.data_ptr(), table.data_ptr(), xr.data_ptr(), ctypes.c_float(0.1),
-                    ctypes.c_float(l1_weight), ctypes.c_float(0.01), loss.data_ptr(), g.data_ptr(), ws.data_ptr(),
-                    ws.numel() * 8, B, S, H, H, st)
+        ins = [_maps(gen, B, H, tied).to(dev) for _ in range(sets)]
+        tgs = [_maps(gen, B, H, tied).to(dev) for _ in range(sets)]
+        grads = [torch.empty_like(a) for a in ins]
+        p_in, p_tg, p_gr = _ptr_array(ins), _ptr_array(tgs), _ptr_array(grads)
+        fn, loop, st = self._fn("svbrdf_mixed_loss_fwd_bwd_host_scenes"), self.loops.perf_loop_loss, _fp(self.sa.cuda_stream)
+        c_f, c_i = ctypes.c_float, ctypes.c_int
 
-            def call(args=args):
-                rc = fn(*args)
-                assert rc == 0, lib.svbrdf_last_error()
-            calls.append(call)
+        def enqueue(first, n):
+            rc = loop(fn, c_i(n), c_i(first), c_i(sets), p_in, p_tg, p_gr, _fp(table.data_ptr()), _fp(xr.data_ptr()), c_f(0.1),
+                      c_f(l1_weight), c_f(0.01), _fp(loss.data_ptr()), _fp(ws.data_ptr()), ctypes.c_size_t(ws.numel() * 8),
+                      c_i(B), c_i(S), c_i(H), c_i(H), st)
+            assert rc == 0, lib.svbrdf_last_error()
         torch.cuda.synchronize(dev)
-        return calls, keep, 144.0 * H * H * B
+        return enqueue, [table, xr, ws, loss, ins, tgs, grads, p_in, p_tg, p_gr], 144.0 * H * H * B
 
     def k12_calls(self, which):
         from svbrdf_estimation_amd import environment
@@ -169,45 +194,44 @@ class Harness:
         torch.manual_seed(7)
         table = environment.BatchSceneSampler(B, 1, 0).sample().to(dev)
         xr = self.native.xrow(dev, H)
-        st = _fp(self.sa.cuda_stream)
+        st, c_i = _fp(self.sa.cuda_stream), ctypes.c_int
         if which == "k1":
             out = torch.empty(B, 1, 3, H, H, device=dev)
-            args = (maps.data_ptr(), table.data_ptr(), xr.data_ptr(), out.data_ptr(), B, 1, H, H, st)
-            fn, nbytes = lib.svbrdf_render_fwd, 60.0 * H * H * B
+            fn, nbytes, keep = self._fn("svbrdf_render_fwd"), 60.0 * H * H * B, [maps, table, xr, out]
+
+            def enqueue(first, n):
+                rc = self.loops.perf_loop_render_fwd(fn, c_i(n), _fp(maps.data_ptr()), _fp(table.data_ptr()), _fp(xr.data_ptr()),
+                                                     _fp(out.data_ptr()), c_i(B), c_i(1), c_i(H), c_i(H), st)
+                assert rc == 0, lib.svbrdf_last_error()
         else:
             cot = torch.randn(B, 1, 3, H, H, device=dev)
             out = torch.empty(B, 12, H, H, device=dev)
-            args = (maps.data_ptr(), table.data_ptr(), xr.data_ptr(), cot.data_ptr(), out.data_ptr(), B, 1, H, H, st)
-            fn, nbytes = lib.svbrdf_render_bwd, 108.0 * H * H * B
-            maps = (maps, cot)
+            fn, nbytes, keep = self._fn("svbrdf_render_bwd"), 108.0 * H * H * B, [maps, table, xr, cot, out]
 
-        def call():
-            rc = fn(*args)
-            assert rc == 0, lib.svbrdf_last_error()
+            def enqueue(first, n):
+                rc = self.loops.perf_loop_render_bwd(fn, c_i(n), _fp(maps.data_ptr()), _fp(table.data_ptr()), _fp(xr.data_ptr()),
+                                                     _fp(cot.data_ptr()), _fp(out.data_ptr()), c_i(B), c_i(1), c_i(H), c_i(H), st)
+                assert rc == 0, lib.svbrdf_last_error()
         torch.cuda.synchronize(dev)
-        return [call], [maps, table, xr, out], nbytes
+        return enqueue, keep, nbytes
 
     def k4_calls(self):
         lib, dev = self.lib, self.dev
-        B, H = 64, 256
+        B, H, sets = 64, 256, 2     # two alternating sets (604 MB), as in bench.py / tools/kernel_cases.py
         gen = torch.Generator().manual_seed(17)
-        lib.svbrdf_mix_materials.argtypes = [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]
-        lib.svbrdf_mix_materials.restype = ctypes.c_int
         alpha = torch.rand(B, device=dev) * 0.8 + 0.1
-        st = _fp(self.sa.cuda_stream)
-        keep, calls = [alpha], []
-        for _ in range(2):          # two alternating sets (604 MB), as in bench.py / tools/kernel_cases.py
-            a, b = _maps(gen, B, H).to(dev), _maps(gen, B, H).to(dev)
-            out = torch.empty_like(a)
-            keep += [a, b, out]
-            args = (a.data_ptr(), b.data_ptr(), alpha.data_ptr(), out.data_ptr(), B, H, H, st)
+        a = [_maps(gen, B, H).to(dev) for _ in range(sets)]
+        b = [_maps(gen, B, H).to(dev) for _ in range(sets)]
+        outs = [torch.empty_like(x) for x in a]
+        p_a, p_b, p_o = _ptr_array(a), _ptr_array(b), _ptr_array(outs)
+        fn, st, c_i = self._fn("svbrdf_mix_materials"), _fp(self.sa.cuda_stream), ctypes.c_int
 
-            def call(args=args):
-                rc = lib.svbrdf_mix_materials(*args)
-                assert rc == 0, lib.svbrdf_last_error()
-            calls.append(call)
+        def enqueue(first, n):
+            rc = self.loops.perf_loop_mix(fn, c_i(n), c_i(first), c_i(sets), p_a, p_b, _fp(alpha.data_ptr()), p_o, c_i(B), c_i(H),
+                                          c_i(H), st)
+            assert rc == 0, lib.svbrdf_last_error()
         torch.cuda.synchronize(dev)
-        return calls, keep, 144.0 * H * H * B
+        return enqueue, [alpha, a, b, outs, p_a, p_b, p_o], 144.0 * H * H * B
 
 
 @pytest.fixture(scope="module")

@@ -26,9 +26,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     dev = torch.device("cuda:0")
     h = Harness(dev)
-    calls, keep, _ = h.k3_calls(8, 256, 3, 6)
-    for _ in range(40):
-        calls[0]()
+    enqueue, keep, _ = h.k3_calls(8, 256, 3, 6)          # enqueue(first, n): n launches from C (tests/c_host/launch_loop.c)
+    enqueue(0, 40)
     torch.cuda.synchronize(dev)
     for mode in ("idle_start", "busy_start", "sustained"):
         n_probe = 60
@@ -36,14 +35,12 @@ def main():
         if mode == "busy_start":            # the GPU has been under this load for 0.3 s when the series starts
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < 0.3:
-                for k in range(32):
-                    calls[k % len(calls)]()
+                enqueue(0, 32)
                 torch.cuda.synchronize(dev)
         elif mode == "sustained":           # 0.6 s of launches with NO synchronisation in between (a training loop's load)
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < 0.6:
-                for k in range(32):
-                    calls[k % len(calls)]()
+                enqueue(0, 32)
         else:
             time.sleep(0.5)
         e_start, e_k0, e_k1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
@@ -53,8 +50,7 @@ def main():
         if mode == "idle_start":
             time.sleep(0.002)
         e_k0.record(h.sa)
-        for k in range(n):
-            calls[k % len(calls)]()
+        enqueue(0, n)
         e_k1.record(h.sa)
         torch.cuda.synchronize(dev)
         k0, k1 = e_start.elapsed_time(e_k0), e_start.elapsed_time(e_k1)
