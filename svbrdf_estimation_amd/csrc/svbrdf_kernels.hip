@@ -17,7 +17,7 @@
 // reproduces the reference's fp32 rounding sequence exactly: products rounded one by one
 // (-ffp-contract=off, no FMA contraction), dot products summed (p0+p1)+p2 like
 // torch.sum(dim=-3), correctly rounded sqrt and division.  Downstream of those values -- and
-// for the three dot products that do not feed NH (n.wo, n.wi, wo.h: SVBRDF_FMA_VN_LN) -- the
+// for the three dot products that do not feed NH (n.wo, n.wi, wo.h) -- the
 // computation is well conditioned and uses explicit FMAs and 1-ULP primitives.
 //
 // Data layout.  Maps stay in the reference's BCHW planar layout (W contiguous): lane l of a
@@ -50,7 +50,7 @@
 //                separate units so that each can take its own set again when the optimum moves)
 //   SVBRDF_TU=4  none of the kernels or entry points of this file: svbrdf_aux_f64.hip (float64 maps, second order:
 //                auxiliary, not on the north-star path) includes it for the shared inline device code and host checks
-// SVBRDF_TU=2 (default; tools/ build the file with one command): units 0, 1 and 3 in one.
+// SVBRDF_TU=2 (default: a one-command build of the file): units 0, 1 and 3 in one.
 #ifndef SVBRDF_TU
 #define SVBRDF_TU 2
 #endif
@@ -62,10 +62,7 @@
 namespace {
 
 constexpr int kThreads = 256;          // 4 waves of 64 (K1, K2)
-#ifndef SVBRDF_K3_THREADS
-#define SVBRDF_K3_THREADS 256
-#endif
-constexpr int kLossThreads = SVBRDF_K3_THREADS;      // K3 workgroup of the unsplit layout (64 / 128: A/B builds)
+constexpr int kLossThreads = 256;      // K3 workgroup (64 and 128 threads: A/B builds of round 4, both slower)
 constexpr float kPi = 3.14159274101257324219f;  // float32(math.pi), renderers.py:20,27
 constexpr float kMinDot = 0.001f;      // renderers.py:48-52
 constexpr float kMinRough = 0.001f;    // renderers.py:87
@@ -82,13 +79,9 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 }
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-#ifndef SVBRDF_ABLATE
-#define SVBRDF_ABLATE 0
-#endif
-// (ablation 8, timing only: every transcendental replaced by one plain multiply)
-__device__ __forceinline__ float rcp_(float x) { return SVBRDF_ABLATE == 8 ? x * 0.9990234375f : __builtin_amdgcn_rcpf(x); }    // v_rcp_f32, 1 ULP
-__device__ __forceinline__ float rsq_(float x) { return SVBRDF_ABLATE == 8 ? x * 1.0009765625f : __builtin_amdgcn_rsqf(x); }    // v_rsq_f32, 1 ULP
-__device__ __forceinline__ float log2_(float x) { return SVBRDF_ABLATE == 8 ? x * 1.0019531250f : __builtin_amdgcn_logf(x); }   // v_log_f32
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32, 1 ULP
+__device__ __forceinline__ float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }    // v_rsq_f32, 1 ULP
+__device__ __forceinline__ float log2_(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
 
 // Correctly rounded a/b for several numerators over ONE denominator: the reciprocal is
 // refined once (v_rcp + 2 FMA, Newton) and shared; each quotient then costs a multiply and
@@ -98,51 +91,25 @@ __device__ __forceinline__ float log2_(float x) { return SVBRDF_ABLATE == 8 ? x 
 // 1e-3 <~ b <~ 1e3 (lengths of camera/light offsets).  svbrdf_debug_check_arith() compares
 // both primitives with the IEEE-correct `/` and sqrtf on the device: 0 mismatches in
 // 3 x 2^31 operand pairs (tests/test_gpu_parity.py).
-// Timing experiments only (tools/ablate.sh builds separate libraries with -DSVBRDF_ABLATE=n; results
-// are WRONG by construction): 1 = inexact geometry (rsq*x instead of exact sqrt/division),
-// 2 = no target shading, 3 = no logs in the loss, 4 = no adjoint, 5 = no GGX/Smith lobe,
-// 6 = no map loads in K3 (values synthesised from the pixel index), 7 = no gradient stores in K3,
-// 8 = every transcendental (v_rcp/v_rsq/v_log) replaced by one plain multiply.
-#ifndef SVBRDF_ABLATE
-#define SVBRDF_ABLATE 0
-#endif
+// (The timing-only ablation builds of round 1 -- inexact geometry, no target shading, no logs, no adjoint, no lobe, no loads,
+// no stores, transcendentals as multiplies: profiles/r01_k3_ablation.txt -- and the per-term log form of the loss are no
+// longer in the source; git show 3d7c7a1 has them.)
 #ifndef SVBRDF_SCALE_BLOCKS
 #define SVBRDF_SCALE_BLOCKS 1024
 #endif
-#ifndef SVBRDF_LOG_PER_TERM
-#define SVBRDF_LOG_PER_TERM 0      // 1: two v_log and one v_rcp per channel, the reference's operation order (A/B builds)
-#endif
 #ifndef SVBRDF_TIMING
-#define SVBRDF_TIMING 0            // 1: timing-only build, see tools/k3_cycles.py
-#endif
-#ifndef SVBRDF_K3_UNROLL2
-#define SVBRDF_K3_UNROLL2 1        // scene loop of the forward+adjoint kernels: two passes per trip, geometry ping-pong
-#endif
-#ifndef SVBRDF_K3_PEEL_LAST
-#define SVBRDF_K3_PEEL_LAST 0      // 1: the last render of a wave is shaded without the (unused) geometry of a successor
+#define SVBRDF_TIMING 0            // 1: timing-only build (per-wave stamps instead of gradients), see tools/k3_timeline.py
 #endif
 // The exact-rounding contract (header of this file) covers the path into NH -- coords, wo, wi, h, n.h, 1 - NH^2 -- because the
 // GGX denominator amplifies NH's last bit by 1e3..1e4.  n.wo, n.wi and wo.h feed only well-conditioned terms (Smith G, the
 // cosine factor, Fresnel): a last-bit difference there moves a radiance by ~1e-7 relative, a hundredth of the 1e-5 bound.
 // They are one multiply + two FMAs instead of the reference's three rounded products and two adds: -10 VALU per render
-// (K3 at config 2: -2 % time, same-box A/B profiles/r04_k3_ab_algebra.txt).  0 restores the op-by-op form (A/B builds).
-#ifndef SVBRDF_FMA_VN_LN
-#define SVBRDF_FMA_VN_LN 1
-#endif
+// (K3 at config 2: -2 % time, same-box A/B profiles/r04_k3_ab_algebra.txt).
 // The 1/pi of the diffuse gradient and dA/dr_hat = 4 r^3 of the roughness gradient are per-pixel constants: applied once
 // after the scene loop instead of once per render and channel (-6 VALU per render; -1.5 % time in the same A/B).
-#ifndef SVBRDF_K3_DEFER_SCALES
-#define SVBRDF_K3_DEFER_SCALES 1
-#endif
 // f = (1-F) d/pi + F GD (renderers.py:18-20, 62-65) evaluated as d/pi + F (GD - d/pi): the difference is shared with the
 // adjoint's d f/d F, -6 VALU per render (-0.5 ... -1.6 % time, profiles/r04_k3_ab_lerp.txt); both maps use the same form,
-// so identical maps still give a loss of exactly 0.  0 restores the two-product form (A/B builds).
-#ifndef SVBRDF_F_AS_LERP
-#define SVBRDF_F_AS_LERP 1
-#endif
-#ifndef SVBRDF_K3_PIPELINE
-#define SVBRDF_K3_PIPELINE 1       // 0: geometry of a render computed in its own pass (no unused geometry after the last render)
-#endif
+// so identical maps still give a loss of exactly 0.
 #ifndef SVBRDF_K3_MIN_WAVES
 #define SVBRDF_K3_MIN_WAVES 4      // waves/SIMD the register allocator must leave room for (128 VGPRs)
 #endif
@@ -153,7 +120,6 @@ struct Recip {
 __device__ __forceinline__ float div_rn(float a, const Recip &r)
 {
     const float q = a * r.y;
-    if (SVBRDF_ABLATE == 1) return q;
     return fma_(fma_(-r.b, q, a), r.y, q);
 }
 
@@ -166,7 +132,6 @@ __device__ __forceinline__ Recip length_rn(float x, float &seed)
     const float y = rsq_(x);
     const float g = x * y;
     seed = y;
-    if (SVBRDF_ABLATE == 1) return Recip{g, y};
     const float len = fma_(fma_(-g, g, x), 0.5f * y, g);
     const float e = fma_(-len, y, 1.0f);
     return Recip{len, fma_(e, y, y)};
@@ -187,14 +152,9 @@ __device__ __forceinline__ float vreg(float c)
     asm volatile("" : "+v"(c));
     return c;
 }
-#ifndef SVBRDF_VCONST
-#define SVBRDF_VCONST 1
-#endif
 __device__ __forceinline__ VConst make_vconst()
 {
-    if (SVBRDF_VCONST)
-        return VConst{vreg(kMinDot), vreg(kPi), vreg(1.0f / kPi), vreg(0.693147180559945309417f), vreg(1.0e30f)};
-    return VConst{kMinDot, kPi, 1.0f / kPi, 0.693147180559945309417f, 1.0e30f};
+    return VConst{vreg(kMinDot), vreg(kPi), vreg(1.0f / kPi), vreg(0.693147180559945309417f), vreg(1.0e30f)};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -228,9 +188,8 @@ __device__ __forceinline__ Geom geometry(const VConst &K, const float sc[9], flo
     const Recip ih = length_rn(dot3(sx, sy, sz, sx, sy, sz), yh);
     g.hx = div_rn(sx, ih); g.hy = div_rn(sy, ih); g.hz = div_rn(sz, ih);
     // from here on the computation is well conditioned: 1-ULP primitives are enough
-    // (wo.h feeds only the Fresnel factor: no exact dot product needed, see SVBRDF_FMA_VN_LN)
-    const float VH = fmaxf(SVBRDF_FMA_VN_LN ? fma_(g.wox, g.hx, fma_(g.woy, g.hy, g.woz * g.hz))
-                                            : dot3(g.wox, g.woy, g.woz, g.hx, g.hy, g.hz), K.tiny);
+    // (wo.h feeds only the Fresnel factor: no exact dot product needed)
+    const float VH = fmaxf(fma_(g.wox, g.hx, fma_(g.woy, g.hy, g.woz * g.hz)), K.tiny);
     const float t = 1.0f - VH;
     const float t2 = t * t;
     g.p = (t2 * t2) * t;
@@ -296,13 +255,8 @@ __device__ __forceinline__ Dots dots(const VConst &K, const Geom &g, const MapK 
 {
     Dots d;
     d.nh_raw = dot3(m.n[0], m.n[1], m.n[2], g.hx, g.hy, g.hz);
-    if (SVBRDF_FMA_VN_LN) {
-        d.vn_raw = fma_(g.wox, m.n[0], fma_(g.woy, m.n[1], g.woz * m.n[2]));
-        d.ln_raw = fma_(g.wix, m.n[0], fma_(g.wiy, m.n[1], g.wiz * m.n[2]));
-    } else {
-        d.vn_raw = dot3(g.wox, g.woy, g.woz, m.n[0], m.n[1], m.n[2]);
-        d.ln_raw = dot3(g.wix, g.wiy, g.wiz, m.n[0], m.n[1], m.n[2]);
-    }
+    d.vn_raw = fma_(g.wox, m.n[0], fma_(g.woy, m.n[1], g.woz * m.n[2]));      // well conditioned: one multiply + two FMAs
+    d.ln_raw = fma_(g.wix, m.n[0], fma_(g.wiy, m.n[1], g.wiz * m.n[2]));
     d.NH = fmaxf(d.nh_raw, K.tiny);
     d.VN = fmaxf(d.vn_raw, K.tiny);
     d.LN = fmaxf(d.ln_raw, K.tiny);
@@ -331,10 +285,6 @@ template <bool BWD>
 __device__ __forceinline__ Lobe lobe(const VConst &K, float A, float oA, const Dots &d)
 {
     Lobe l;
-    if (SVBRDF_ABLATE == 5) {
-        l.GD = A * d.VN2; l.KA = d.LN2; l.KV = A; l.KL = d.NH2; l.KN = d.oN;
-        return l;
-    }
     const float yV = fma_(d.VN2, oA, A), yL = fma_(d.LN2, oA, A);
     // sqrt as y*rsq(y) in the forward-only and the forward+backward instantiation alike, so
     // that input and target shading are the SAME arithmetic (identical maps -> loss exactly 0)
@@ -375,12 +325,8 @@ __device__ __forceinline__ void shade(const VConst &K, const Geom &g, const MapK
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         F[k] = fma_(m.oms[k], g.p, m.s[k]);                               // Schlick, renderers.py:29-32
-        if (SVBRDF_F_AS_LERP) {                                           // f = d/pi + F (GD - d/pi): one instruction fewer
-            f[k] = fma_(F[k], lb[NL == 3 ? k : 0].GD - m.dpi[k], m.dpi[k]);
-        } else {
-            const float spec = F[k] * lb[NL == 3 ? k : 0].GD;               // GD carries the 1/(4 VN LN)
-            f[k] = fma_(1.0f - F[k], m.dpi[k], spec);                     // renderers.py:18-20, 62-65
-        }
+        // f = (1-F) d/pi + F GD (renderers.py:18-20, 62-65; GD carries the 1/(4 VN LN)) as d/pi + F (GD - d/pi)
+        f[k] = fma_(F[k], lb[NL == 3 ? k : 0].GD - m.dpi[k], m.dpi[k]);
         rad[k] = f[k] * (g.E[k] * d.LNp);
     }
 }
@@ -404,8 +350,7 @@ __device__ __forceinline__ void shade_bwd(const VConst &K, const Geom &g, const 
         const float gE = g_rad[k] * g.E[k];
         const float g_f = gE * d.LNp;
         g_LNp = k == 0 ? gE * f[k] : fma_(gE, f[k], g_LNp);
-        const float g_F = SVBRDF_F_AS_LERP ? g_f * (l.GD - m.dpi[k])
-                                           : fma_(g_f, l.GD, -(g_f * m.dpi[k]));   // f = (1-F) d/pi + F GD
+        const float g_F = g_f * (l.GD - m.dpi[k]);                        // f = d/pi + F (GD - d/pi)
         acc.s[k] = fma_(g_F, omp, acc.s[k]);
         acc.d[k] = DEFER_D ? fma_(g_f, 1.0f - F[k], acc.d[k]) : fma_(g_f * (1.0f - F[k]), inv_pi, acc.d[k]);
         const float gGD = g_f * F[k];                                     // d loss/d GD
@@ -517,13 +462,10 @@ __device__ __forceinline__ void store_grads(float *__restrict__ base, size_t pla
 // as the scalar offset operand -- all address arithmetic on the scalar unit.  With flat 64-bit addresses the compiler
 // spends ~100 VALU instructions per pixel on v_mad_u64_u32 / v_lshl_add_u64 pairs, in a kernel that is bound by VALU
 // issue.  One item's planes must stay below 2 GiB (checked on the host: H*W <= 2^25).
-#ifndef SVBRDF_K3_ADDR32
-#define SVBRDF_K3_ADDR32 1
-#endif
 #ifndef SVBRDF_K3_STORE_AUX
 // Cache policy of K3's gradient stores: sc0 sc1 = write-through.  A launch cannot end before its dirty lines have left
 // the eight XCDs' L2s; with plain stores the 25 MB of gradients of config 2 pile up there and the release at the end of
-// the kernel costs ~1.4 us (same-box A/B, profiles/r04_ab_micro.txt: 38.2 -> 36.8 us per launch one at a time, equal
+// the kernel costs ~1.4 us (same-box A/B, profiles/r04_k3_ab.txt: 38.2 -> 36.8 us per launch one at a time, equal
 // with two launches in flight; nt alone gains 1.1).  A/B builds: 0 = plain, 2 = nt, 17 = sc0 sc1, 19 = all three.
 #define SVBRDF_K3_STORE_AUX 17
 #endif
@@ -556,12 +498,6 @@ __device__ __forceinline__ void plane_store(const PlaneBuf &p, int k, float v)
 
 __device__ __forceinline__ void load_maps_k3(const float *__restrict__ base, size_t plane, size_t pix, Maps &m)
 {
-    if (!SVBRDF_K3_ADDR32) {
-        Maps t[1];
-        load_maps<1>(base, plane, pix, t);
-        m = t[0];
-        return;
-    }
     const PlaneBuf p = plane_buf(base, 12, plane, pix);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -574,11 +510,6 @@ __device__ __forceinline__ void load_maps_k3(const float *__restrict__ base, siz
 
 __device__ __forceinline__ void store_grads_k3(float *__restrict__ base, size_t plane, size_t pix, const Grad &g)
 {
-    if (!SVBRDF_K3_ADDR32) {
-        const Grad t[1] = {g};
-        store_grads<1>(base, plane, pix, t);
-        return;
-    }
     const PlaneBuf p = plane_buf(base, 12, plane, pix);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -587,20 +518,6 @@ __device__ __forceinline__ void store_grads_k3(float *__restrict__ base, size_t 
         plane_store(p, 6 + k, g.r[k]);
         plane_store(p, 9 + k, g.s[k]);
     }
-}
-
-// With the L1 terms behind a wave-uniform branch (scene-split workgroups: wave 0 only), the compiler re-issues the plane
-// loads inside the branch instead of keeping the values (loads from __restrict__ const memory are rematerialisable), each
-// followed by its own s_waitcnt: the prologue then serialises a dozen memory latencies.  An empty asm that "modifies"
-// the loaded value makes it an ordinary register value.
-__device__ __forceinline__ void pin_loaded(float *v, int n)
-{
-#pragma unroll
-    for (int i = 0; i < n; ++i) asm volatile("" : "+v"(v[i]));
-}
-__device__ __forceinline__ void pin_maps(Maps &m)
-{
-    pin_loaded(m.n, 3); pin_loaded(m.d, 3); pin_loaded(m.r, 3); pin_loaded(m.s, 3);
 }
 
 __device__ __forceinline__ void zero_grad(Grad &g)
@@ -836,9 +753,6 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 constexpr int kLossSlots = 64;                    // sharded accumulators (power of two)
-#ifndef SVBRDF_K3_SPLIT_VARIANTS
-#define SVBRDF_K3_SPLIT_VARIANTS 0                // 1: also build the scene-split workgroup layouts (experiment, see below)
-#endif
 constexpr int kLossCountShift = 48;               // word = arrivals << 48 | fixed-point sum
 constexpr unsigned long long kLossSumMask = (1ULL << kLossCountShift) - 1;
 constexpr unsigned long long kLossTicketMask = 0xffffffffULL;   // ws[kLossSlots]: low half counts slot completions,
@@ -850,9 +764,7 @@ __device__ __forceinline__ void loss_pixel_scene(const VConst &K, const Geom &g,
                                                  const MapK &mt, float eps, float inv_count, float &lsum, Grad &acc)
 {
     float rt[3];
-    if (SVBRDF_ABLATE == 2) {
-        rt[0] = mt.dpi[0] * g.p; rt[1] = mt.dpi[1] * g.p; rt[2] = mt.dpi[2] * g.p;
-    } else {
+    {
         const Dots dt = dots(K, g, mt);
         Lobe lt[NL];
         float Ft[3], ft[3];
@@ -864,7 +776,7 @@ __device__ __forceinline__ void loss_pixel_scene(const VConst &K, const Geom &g,
     shade<NL, WITH_GRAD>(K, g, mi, di, li, Fi, fi, ri);
     // losses.py:46-50: |log(ri + eps) - log(rt + eps)| and its derivative sign/(N (ri + eps)).
     // Transcendentals are what this kernel pays most for (~16 issue cycles each against ~2.5 for a
-    // plain instruction once several waves share the SIMD: tools/k3_cycles.py),
+    // plain instruction once several waves share the SIMD: profiles/r01_k3_cycles.txt),
     // so the nine of the reference's formulation (six logs, three reciprocals) are done with four:
     //  * the three 1/ai come from ONE v_rcp of their product (6 multiplies).  Operands are scaled
     //    by 2^-10 (exact) so that the product stays in range for eps <= ai <= 7e15, eps >= 1e-9
@@ -878,10 +790,7 @@ __device__ __forceinline__ void loss_pixel_scene(const VConst &K, const Geom &g,
         float b[3], bt[3], ib[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { b[k] = fma_(ri[k], c, ec); bt[k] = fma_(rt[k], c, ec); }   // = (r + eps) * c, one rounding
-        if (SVBRDF_LOG_PER_TERM) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) ib[k] = rcp_(b[k]);
-        } else {
+        {
             const float P = b[0] * b[1];
             const float r = rcp_(P * b[2]);
             const float t = r * b[2];
@@ -889,15 +798,6 @@ __device__ __forceinline__ void loss_pixel_scene(const VConst &K, const Geom &g,
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            if (SVBRDF_ABLATE == 3 || SVBRDF_LOG_PER_TERM) {
-                float delta;
-                if (SVBRDF_ABLATE == 3) delta = b[k] - bt[k];
-                else delta = K.ln2 * (log2_(b[k]) - log2_(bt[k]));     // the reference's operation order
-                lsum += fabsf(delta) * (1.0f / 0.693147180559945309417f);
-                const float sg = __builtin_amdgcn_fmed3f(delta * K.huge, -1.0f, 1.0f);
-                g_rad[k] = sg * (nc * ib[k]);
-                continue;
-            }
             // lg = log2(at/ai) = -(log(ai) - log(at))/ln2.  The loss sums |lg| (scaled by ln2 ONCE, after the scene
             // loop); d|delta|/d ri = sign(delta)/(N ai) = -sign(lg) nc/b: the magnitude nc*ib takes lg's sign bit with
             // one v_and_or, and the minus rides as a source modifier on the product that consumes it.  sign(0) = 0 as in
@@ -910,11 +810,7 @@ __device__ __forceinline__ void loss_pixel_scene(const VConst &K, const Geom &g,
             g_rad[k] = -__builtin_bit_cast(float, __builtin_bit_cast(unsigned, mag) | (__builtin_bit_cast(unsigned, lg) & 0x80000000u));
         }
     }
-    if (SVBRDF_ABLATE == 4) {
-        acc.n[0] += g_rad[0]; acc.n[1] += g_rad[1]; acc.n[2] += g_rad[2];
-    } else if (WITH_GRAD) {
-        shade_bwd<NL, (DEFER & 1) != 0, (DEFER & 2) != 0>(K, g, mi, di, li, Fi, fi, g_rad, acc);
-    }
+    if (WITH_GRAD) shade_bwd<NL, (DEFER & 1) != 0, (DEFER & 2) != 0>(K, g, mi, di, li, Fi, fi, g_rad, acc);
 }
 
 // The same for independent roughness channels (three lobes per map), one colour channel after the other: target lobe,
@@ -937,11 +833,11 @@ __device__ __forceinline__ void loss_pixel_scene_by_channel(const VConst &K, con
     for (int k = 0; k < 3; ++k) {
         const Lobe lt = lobe<false>(K, mt.A[k], mt.oA[k], dt);
         const float Ft = fma_(mt.oms[k], g.p, mt.s[k]);
-        const float ft = SVBRDF_F_AS_LERP ? fma_(Ft, lt.GD - mt.dpi[k], mt.dpi[k]) : fma_(1.0f - Ft, mt.dpi[k], Ft * lt.GD);
+        const float ft = fma_(Ft, lt.GD - mt.dpi[k], mt.dpi[k]);
         const float rt = ft * (g.E[k] * dt.LNp);
         const Lobe li = lobe<WITH_GRAD>(K, mi.A[k], mi.oA[k], di);
         const float Fi = fma_(mi.oms[k], g.p, mi.s[k]);
-        const float fi = SVBRDF_F_AS_LERP ? fma_(Fi, li.GD - mi.dpi[k], mi.dpi[k]) : fma_(1.0f - Fi, mi.dpi[k], Fi * li.GD);
+        const float fi = fma_(Fi, li.GD - mi.dpi[k], mi.dpi[k]);
         const float ri = fi * (g.E[k] * di.LNp);
         const float b = fma_(ri, c, ec), bt = fma_(rt, c, ec);
         const float ib = rcp_(b);
@@ -953,7 +849,7 @@ __device__ __forceinline__ void loss_pixel_scene_by_channel(const VConst &K, con
             const float gE = g_rad * g.E[k];
             const float g_f = gE * di.LNp;
             g_LNp = fma_(gE, fi, g_LNp);
-            const float g_F = SVBRDF_F_AS_LERP ? g_f * (li.GD - mi.dpi[k]) : fma_(g_f, li.GD, -(g_f * mi.dpi[k]));
+            const float g_F = g_f * (li.GD - mi.dpi[k]);
             acc.s[k] = fma_(g_F, omp, acc.s[k]);
             acc.d[k] = (DEFER & 1) ? fma_(g_f, 1.0f - Fi, acc.d[k]) : fma_(g_f * (1.0f - Fi), K.inv_pi, acc.d[k]);
             const float gGD = g_f * Fi;
@@ -976,14 +872,11 @@ __device__ __forceinline__ void loss_pixel_scene_by_channel(const VConst &K, con
     }
 }
 
-#ifndef SVBRDF_UNTIED_BY_CHANNEL
-#define SVBRDF_UNTIED_BY_CHANNEL 1
-#endif
 template <int NL, bool WITH_GRAD, int DEFER = 0>
 __device__ __forceinline__ void loss_pixel_scene_any(const VConst &K, const Geom &g, const MapK &mi, const MapK &mt,
                                                      float eps, float inv_count, float &lsum, Grad &acc)
 {
-    if (NL == 3 && SVBRDF_UNTIED_BY_CHANNEL && SVBRDF_ABLATE == 0)
+    if (NL == 3)
         loss_pixel_scene_by_channel<WITH_GRAD, DEFER>(K, g, mi, mt, eps, inv_count, lsum, acc);
     else
         loss_pixel_scene<NL, WITH_GRAD, DEFER>(K, g, mi, mt, eps, inv_count, lsum, acc);
@@ -1002,52 +895,21 @@ __device__ __forceinline__ void loss_pixel_scene_any(const VConst &K, const Geom
 // The adjoint kernel sits at the 128-VGPR limit of 4 waves/SIMD and spills a little either way; the
 // LDS variant keeps the scalars live across the interleaved streams and spills more.  So: LDS for
 // the forward-only kernels, prefetched global loads for the forward+adjoint kernels.
-// Issue priority in the tail of a launch (experiment, default off).  The SIMD arbitrates by user priority first, age
-// second.  By age alone the oldest wave of a SIMD runs at its lone speed and the youngest gets the leftovers, so the last
-// four waves of every SIMD finish one by one ~3 us apart and the very last runs alone for ~3.5 us at half the SIMD's
-// issue rate (tools/k3_timeline.py).  SVBRDF_K3_TAIL_PRIO = 1: waves of the LAST resident round (workgroups
-// >= nblocks - SVBRDF_K3_CAPACITY) take priority 2 / 1 / 0 by the third of their renders they are in (more remaining =
-// higher), all earlier waves priority 3: the last round's waves converge and finish together, nothing else changes.
-// = 2: every wave by remaining work (round 1's experiment: the rounds then start in lockstep).
-#ifndef SVBRDF_K3_TAIL_PRIO
-#define SVBRDF_K3_TAIL_PRIO 0
-#endif
+// Rejected with same-box evidence in round 4 and no longer in the source (HISTORY.md A.1; git show 3d7c7a1 has them): issue
+// priorities by remaining work in the tail of a launch (s_setprio), a peeled last pass without the unused successor
+// geometry, the un-pipelined and the rolled loop, and re-loading the target maps in every pass.
 #ifndef SVBRDF_K3_STAGGER
 #define SVBRDF_K3_STAGGER 64        // s_sleep units (64 cycles) between the load layers of a launch's first round; 0 = off
-#endif
-#ifndef SVBRDF_K3_STAGGER_LAYERS
-#define SVBRDF_K3_STAGGER_LAYERS 4
 #endif
 #ifndef SVBRDF_K3_EARLY_COORDS
 #define SVBRDF_K3_EARLY_COORDS 1    // pixel coordinates loaded in front of the plane loads (rendering_loss_body)
 #endif
-#ifndef SVBRDF_K3_CAPACITY
-#define SVBRDF_K3_CAPACITY 1024     // resident 256-thread workgroups: 256 CUs x 4
-#endif
-__device__ __forceinline__ void tail_prio(bool in_tail, int remaining, int third)
-{
-    if (!SVBRDF_K3_TAIL_PRIO || !in_tail) return;
-    if (remaining > 2 * third) __builtin_amdgcn_s_setprio(2);
-    else if (remaining > third) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-}
-
-#ifndef SVBRDF_K3_REMAT_TARGET
-#define SVBRDF_K3_REMAT_TARGET 0      // experiment: reload + re-prepare the target maps in every pass
-#endif
-struct RematTarget {                  // where the target's planes of this pixel live (experiment only)
-    const float *base;
-    size_t plane, pix;
-};
-
-template <int NL, bool WITH_GRAD, int G = 1, int DEFER = 0>
+template <int NL, bool WITH_GRAD, int DEFER = 0>
 __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt_in, float x, float y,
                                                  const float *__restrict__ scp, const float *sc_lds, int S,
-                                                 float eps, float inv_count, Grad &acc, RematTarget rt = RematTarget{nullptr, 0, 0})
+                                                 float eps, float inv_count, Grad &acc)
 {
-    // G > 1 (scene-split workgroups, k_rendering_loss_split): this wave shades every G-th render of the item, `scp`
-    // points at its first row and `S` is the number of renders it owns; consecutive rows of the wave are ST floats apart
-    constexpr int ST = 9 * G;
+    constexpr int ST = 9;               // floats per scene row
     float lsum = 0.0f;
     const VConst K = make_vconst();
     eps = vreg(eps);
@@ -1057,13 +919,6 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt_
     const long long tm0 = clock64(), wc0 = wall_clock64();
 #endif
     if (WITH_GRAD) {
-        [[maybe_unused]] bool in_tail = SVBRDF_K3_TAIL_PRIO == 2;
-        [[maybe_unused]] const int third = (S + 2) / 3;
-        if (SVBRDF_K3_TAIL_PRIO == 1) {
-            const unsigned nblocks = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
-            in_tail = bid + SVBRDF_K3_CAPACITY >= nblocks;
-            if (!in_tail) __builtin_amdgcn_s_setprio(3);
-        }
         load_scene(scp, sc);
         Geom ga = geometry(K, sc, x, y), gb;                     // render 0
         load_scene(scp + (S > 1 ? ST : 0), sc);                  // scalars of render 1
@@ -1072,7 +927,6 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt_
         // from a "next" to a "current" register set (9 v_mov per render in the rolled loop).
 #define SVBRDF_K3_PASS(G_CUR, G_NEXT, SI)                                                                             \
         {                                                                                                          \
-            tail_prio(in_tail, S - (SI), third);                                                                   \
             asm volatile("" ::"s"(sc[0]), "s"(sc[8]));           /* the wait for sc lands here, before the next loads */ \
             float cur[9];                                                                                          \
             _Pragma("unroll") for (int i = 0; i < 9; ++i) cur[i] = sc[i];                                          \
@@ -1081,56 +935,13 @@ __device__ __forceinline__ float loss_scene_loop(const MapK &mi, const MapK &mt_
             __builtin_amdgcn_sched_barrier(0);                                                                     \
             /* two independent streams from here to the end of the pass: */                                        \
             G_NEXT = geometry(K, cur, x, y);                     /* render s+1 (a harmless repeat on the last pass) */ \
-            if (SVBRDF_K3_REMAT_TARGET && NL == 1) {                                                               \
-                unsigned opaque = 0;                                                                               \
-                asm volatile("" : "+v"(opaque));                 /* keeps the reload inside the loop */             \
-                Maps tm;                                                                                           \
-                load_maps_k3(rt.base, rt.plane, rt.pix + opaque, tm);                                              \
-                const MapK mt = prepare<false>(tm);                                                                \
-                loss_pixel_scene_any<NL, WITH_GRAD, DEFER>(K, G_CUR, mi, mt, eps, inv_count, lsum, acc);                  \
-            } else {                                                                                               \
-                loss_pixel_scene_any<NL, WITH_GRAD, DEFER>(K, G_CUR, mi, mt_in, eps, inv_count, lsum, acc);               \
-            }                                                                                                      \
+            loss_pixel_scene_any<NL, WITH_GRAD, DEFER>(K, G_CUR, mi, mt_in, eps, inv_count, lsum, acc);                   \
         }
-        if (!SVBRDF_K3_PIPELINE) {
-            // every render in its own pass: scalars of render s+1 prefetched, geometry of render s, shading of render s
-            for (int s = 0; s < S; ++s) {
-                asm volatile("" ::"s"(sc[0]), "s"(sc[8]));
-                float cur[9];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) cur[i] = sc[i];
-                load_scene(scp + (s + 2 < S ? 2 * ST : (s + 1 < S ? ST : 0)), sc);
-                scp += (s + 1 < S) ? ST : 0;
-                loss_pixel_scene_any<NL, WITH_GRAD, DEFER>(K, ga, mi, mt_in, eps, inv_count, lsum, acc);
-                if (s + 1 < S) ga = geometry(K, cur, x, y);
-            }
-        } else if (SVBRDF_K3_UNROLL2 && SVBRDF_K3_PEEL_LAST) {
-            // the last render of the wave has no successor whose geometry could ride along: it is shaded by a copy of
-            // the pass without the pipelined half (one copy per parity of S) instead of recomputing a geometry nobody
-            // uses (~60 VALU + 3 transcendentals per pixel)
-            int s = 0;
-            for (; s + 2 < S; s += 2) {                          // whole trips: two pipelined passes each
-                SVBRDF_K3_PASS(ga, gb, s)
-                SVBRDF_K3_PASS(gb, ga, s + 1)
-            }
-            if (s + 1 < S) {                                     // S - s == 2
-                SVBRDF_K3_PASS(ga, gb, s)
-                loss_pixel_scene_any<NL, WITH_GRAD, DEFER>(K, gb, mi, mt_in, eps, inv_count, lsum, acc);
-            } else {                                             // S - s == 1
-                loss_pixel_scene_any<NL, WITH_GRAD, DEFER>(K, ga, mi, mt_in, eps, inv_count, lsum, acc);
-            }
-        } else if (SVBRDF_K3_UNROLL2) {
-            for (int s = 0;;) {
-                SVBRDF_K3_PASS(ga, gb, s)
-                if (++s >= S) break;
-                SVBRDF_K3_PASS(gb, ga, s)
-                if (++s >= S) break;
-            }
-        } else {
-            for (int s = 0; s < S; ++s) {
-                SVBRDF_K3_PASS(ga, gb, s)
-                ga = gb;
-            }
+        for (int s = 0;;) {
+            SVBRDF_K3_PASS(ga, gb, s)
+            if (++s >= S) break;
+            SVBRDF_K3_PASS(gb, ga, s)
+            if (++s >= S) break;
         }
 #undef SVBRDF_K3_PASS
     } else {
@@ -1219,14 +1030,6 @@ __device__ __forceinline__ void head_bwd(const Head &h, const Grad &g, float ge[
     ge[5] = 0.5f * ((g.r[0] + g.r[1]) + g.r[2]);
 }
 
-// ablation 6 only: plausible map values without touching memory
-__device__ __forceinline__ void fake_maps(size_t pix, float shift, Maps &m)
-{
-    const float t = (float)(pix & 1023) * (1.0f / 2048.0f) + shift;     // [0, 0.55)
-    m.n[0] = 0.1f * t; m.n[1] = 0.2f - 0.1f * t; m.n[2] = 0.97f;
-    for (int k = 0; k < 3; ++k) { m.d[k] = 0.2f + 0.5f * t; m.r[k] = 0.3f + t; m.s[k] = 0.1f + 0.25f * t * (float)(k + 1); }
-}
-
 // Loss reduction, workgroup level: one lane adds its workgroup's partial sum `t` (fixed point) to the workgroup's slot
 // with ONE returning atomic that also counts the slot's arrivals; returns true for the workgroup that completed the
 // last slot of the launch (the finisher).
@@ -1282,37 +1085,26 @@ __device__ __forceinline__ void loss_finish(unsigned lane, unsigned long long *_
 // the gradient planes of one pixel: 12 channels, or the 9 of the encoded head output (chain rule through decode_head)
 template <bool HEAD>
 __device__ __forceinline__ void store_pixel_grad(const Head &head, const Grad &acc, float *__restrict__ grad_input, int b,
-                                                 size_t plane, size_t pix, [[maybe_unused]] float lsum)
+                                                 size_t plane, size_t pix)
 {
     if (HEAD) {
         float ge[9];
         head_bwd(head, acc, ge);
         float *__restrict__ gp = grad_input + (size_t)b * 9 * plane;
-        if (SVBRDF_K3_ADDR32) {
-            const PlaneBuf pb = plane_buf(gp, 9, plane, pix);
+        const PlaneBuf pb = plane_buf(gp, 9, plane, pix);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) plane_store(pb, k, ge[k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) gp[(size_t)k * plane + pix] = ge[k];
-        }
+        for (int k = 0; k < 9; ++k) plane_store(pb, k, ge[k]);
     } else {
-        if (SVBRDF_ABLATE != 7 || lsum == -12345.0f)
-            store_grads_k3(grad_input + (size_t)b * 12 * plane, plane, pix, acc);
+        store_grads_k3(grad_input + (size_t)b * 12 * plane, plane, pix, acc);
     }
 }
 
-// G == 1: one thread = one pixel, all S renders of it (VEC = 1: the kernel is VALU-bound, wider loads measured no gain
-// and cost occupancy); workgroup = 256 pixels.
-// G > 1 (forward+adjoint kernels only, k_rendering_loss_split): workgroup = 64 pixels x G waves.  Wave g shades renders
-// g, g+G, g+2G, ... of every pixel of the block; waves 1..G-1 hand their 12 gradient partials and their loss partial to
-// wave 0 through LDS, which adds them IN WAVE ORDER (bitwise reproducible), stores the gradient and takes part in the loss
-// reduction.  Same bytes from HBM (the G waves read the same 24 plane lines: one miss, G-1 hits in the CU's cache or L2),
-// G times the per-pixel prologue, but G times as many, G times shorter waves: a launch of config 2 is 6 resident rounds of
-// short waves instead of 2 rounds of long ones, whose first round starts behind ONE burst of all its loads and whose last
-// waves run alone on their SIMDs at half the issue rate.
-// WITH_L1 adds SVBRDFL1Loss on the 24 values already in registers (wave 0 only when G > 1).
-template <bool WITH_GRAD, bool WITH_L1, bool HEAD, int G = 1, bool EARLY_COORDS = false>
+// One thread = one pixel, all S renders of it (VEC = 1: the kernel is VALU-bound, wider loads measured no gain and cost
+// occupancy); workgroup = 256 pixels.  (Round 4 also built workgroups of 64 pixels x G waves that share the renders of a
+// pixel -- more, shorter waves against the ramp and tail of a launch -- and rejected them: the per-wave fixed work is worth
+// 0.75 renders, profiles/r04_k3_ab.txt, HISTORY.md A.1; the variant is in the history, git show 3d7c7a1.)
+// WITH_L1 adds SVBRDFL1Loss on the 24 values already in registers.
+template <bool WITH_GRAD, bool WITH_L1, bool HEAD, bool EARLY_COORDS = false>
 __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ input, const float *__restrict__ target,
                                                     const float *__restrict__ scenes, const float *__restrict__ xrow,
                                                     float eps, float inv_count, double loss_scale, float fixed_scale,
@@ -1320,13 +1112,10 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
                                                     unsigned long long *__restrict__ ws, float *__restrict__ loss_out,
                                                     int S, int H, int W)
 {
-    static_assert(G == 1 || WITH_GRAD, "scene-split workgroups exist for the forward+adjoint kernels only");
     extern __shared__ __attribute__((aligned(16))) float sc_lds[];      // [S][9] scene scalars of batch item b
     constexpr float kLn2 = 0.693147180559945309417f;
     const size_t plane = (size_t)H * W;
-    const int grp = G == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // wave-uniform
-    const unsigned lane = G == 1 ? threadIdx.x : (threadIdx.x & 63u);
-    const size_t pix = (size_t)blockIdx.x * (G == 1 ? kLossThreads : 64) + lane;
+    const size_t pix = (size_t)blockIdx.x * kLossThreads + threadIdx.x;
     const int b = blockIdx.y;
     const bool active = pix < plane;
     float lsum = 0.0f;
@@ -1336,7 +1125,7 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
     const long long t_entry = wall_clock64();
 #endif
 #if SVBRDF_K3_STAGGER
-    if (WITH_GRAD && G == 1 && EARLY_COORDS && S >= 6) {     // (by-value-table kernels only, like the early coordinate loads)
+    if (WITH_GRAD && EARLY_COORDS && S >= 6) {     // (by-value-table kernels only, like the early coordinate loads)
         // The first resident round of a launch -- 1024 workgroups, 4096 waves -- issues 25 MB of plane loads within 0.4 us,
         // and when the maps come from HBM every one of those waves gets its last plane at about the same time, 4-5 us
         // later: nobody computes until then.  Issued in four layers (workgroup >> 8 = which of a CU's four workgroup
@@ -1349,18 +1138,10 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         // variants; eight or sixteen finer layers: no better, r04_k3_ab_stagger_layers.txt).  Only for launches whose
         // waves live long enough (>= 6 renders per pixel: the reference's loss has 9, config 5 has 32).  A different
         // placement order would make this a harmless delay, not an error.
-#if SVBRDF_K3_STAGGER_LAYERS == 4
         const unsigned layer = (blockIdx.y * gridDim.x + blockIdx.x) >> 8;
         if (layer == 1) __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER);
         else if (layer == 2) { __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); }
         else if (layer == 3) { __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER); }
-#else   // experiment: finer layers (8 or 16 per resident round), the delay applied layer times
-        const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
-        if (bid < 1024u) {
-            const unsigned layer = bid / (1024u / SVBRDF_K3_STAGGER_LAYERS);
-            for (unsigned i = 0; i < layer; ++i) __builtin_amdgcn_s_sleep(SVBRDF_K3_STAGGER);
-        }
-#endif
     }
 #endif
     if (!WITH_GRAD) {    // forward-only kernels stage the scene table of batch item b in LDS (see loss_scene_loop)
@@ -1391,30 +1172,20 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         if (HEAD) {     // input is the [B,9,H,W] post-tanh generator output
             float e[9];
             const float *__restrict__ ip = input + (size_t)b * 9 * plane;
-            if (SVBRDF_K3_ADDR32) {
-                const PlaneBuf pb = plane_buf(ip, 9, plane, pix);
+            const PlaneBuf pb = plane_buf(ip, 9, plane, pix);
 #pragma unroll
-                for (int k = 0; k < 9; ++k) e[k] = plane_load(pb, k);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) e[k] = ip[(size_t)k * plane + pix];
-            }
-            if (G > 1 && WITH_L1) pin_loaded(e, 9);
+            for (int k = 0; k < 9; ++k) e[k] = plane_load(pb, k);
             head = decode_head(e, in[0]);
         } else {
-            if (SVBRDF_ABLATE == 6) fake_maps(pix, 0.0f, in[0]);
-            else load_maps_k3(input + (size_t)b * 12 * plane, plane, pix, in[0]);
-            if (G > 1 && WITH_L1) pin_maps(in[0]);
+            load_maps_k3(input + (size_t)b * 12 * plane, plane, pix, in[0]);
         }
-        if (SVBRDF_ABLATE == 6) fake_maps(pix, 0.05f, tg[0]);
-        else load_maps_k3(target + (size_t)b * 12 * plane, plane, pix, tg[0]);
-        if (G > 1 && WITH_L1) pin_maps(tg[0]);
+        load_maps_k3(target + (size_t)b * 12 * plane, plane, pix, tg[0]);
         zero_grad(acc);
         float l1sum = 0.0f;
         // deferred per-pixel constants of the adjoint (shade_bwd): 1/pi of the diffuse gradient always (an L1 start value
         // is multiplied by pi here), dA/dr_hat of the roughness gradient only where acc.r starts from zero (it can be 0)
-        constexpr int kDefer = (SVBRDF_K3_DEFER_SCALES && WITH_GRAD && G == 1) ? (WITH_L1 ? 1 : 3) : 0;
-        if (WITH_L1 && (G == 1 || grp == 0)) {
+        constexpr int kDefer = WITH_GRAD ? (WITH_L1 ? 1 : 3) : 0;
+        if (WITH_L1) {
             // losses.py:7-19.  Same economy of transcendentals as in loss_pixel_scene: the six 1/(x + eps)
             // of the log terms' derivatives come from ONE v_rcp of their product (all six lie in
             // [eps_l1, 1 + eps_l1]: no scaling needed), and log(a) - log(b) is one log of the quotient formed
@@ -1425,10 +1196,7 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
                 a[k] = in[0].d[k] + l1.eps; b[k] = tg[0].d[k] + l1.eps;
                 a[3 + k] = in[0].s[k] + l1.eps; b[3 + k] = tg[0].s[k] + l1.eps;
             }
-            if (SVBRDF_LOG_PER_TERM) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) ia[k] = rcp_(a[k]);
-            } else {
+            {
                 float pre[6];               // prefix products a0, a0 a1, ...
                 pre[0] = a[0];
 #pragma unroll
@@ -1441,14 +1209,8 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float dn = in[0].n[k] - tg[0].n[k], dr = in[0].r[k] - tg[0].r[k];
-                float dd, ds;
-                if (SVBRDF_LOG_PER_TERM) {
-                    dd = kLn2 * (log2_(a[k]) - log2_(b[k]));
-                    ds = kLn2 * (log2_(a[3 + k]) - log2_(b[3 + k]));
-                } else {
-                    dd = (a[k] == b[k]) ? 0.0f : -kLn2 * log2_(b[k] * ia[k]);
-                    ds = (a[3 + k] == b[3 + k]) ? 0.0f : -kLn2 * log2_(b[3 + k] * ia[3 + k]);
-                }
+                const float dd = (a[k] == b[k]) ? 0.0f : -kLn2 * log2_(b[k] * ia[k]);
+                const float ds = (a[3 + k] == b[3 + k]) ? 0.0f : -kLn2 * log2_(b[3 + k] * ia[3 + k]);
                 l1sum += (fabsf(dn) + fabsf(dr)) + (fabsf(dd) + fabsf(ds));
                 if (WITH_GRAD) {
                     acc.n[k] = signed_scale(dn, l1.grad_scale);
@@ -1486,61 +1248,21 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
                               (((tg[0].n[0] + tg[0].n[1]) + (tg[0].n[2] + tg[0].r[0])) + (tg[0].r[1] + tg[0].r[2]));
             x[0] += chk - chk;
         }
-        // renders of this wave: all S of the item (G == 1), or rows grp, grp + G, ... of it
-        const int S_own = G == 1 ? S : (S - grp + G - 1) / G;
-        const float *__restrict__ scp = scenes + ((size_t)b * S + grp) * 9;
-        if (G == 1 || S_own > 0) {
-            if (__all(tied))     // wave-uniform: every lane's input AND target roughness channels are tied
-                lsum = loss_scene_loop<1, WITH_GRAD, G, kDefer>(mi, mt, x[0], y, scp, sc_lds, S_own, eps, inv_count, acc,
-                                                                RematTarget{target + (size_t)b * 12 * plane, plane, pix});
-            else
-                lsum = loss_scene_loop<3, WITH_GRAD, G, kDefer>(mi, mt, x[0], y, scp, sc_lds, S_own, eps, inv_count, acc);
-        }
+        const float *__restrict__ scp = scenes + (size_t)b * S * 9;
+        if (__all(tied))     // wave-uniform: every lane's input AND target roughness channels are tied
+            lsum = loss_scene_loop<1, WITH_GRAD, kDefer>(mi, mt, x[0], y, scp, sc_lds, S, eps, inv_count, acc);
+        else
+            lsum = loss_scene_loop<3, WITH_GRAD, kDefer>(mi, mt, x[0], y, scp, sc_lds, S, eps, inv_count, acc);
         if (WITH_L1) lsum = fma_(l1sum, l1.sum_scale, lsum);
 #if SVBRDF_TIMING
         if (WITH_GRAD && !HEAD) {       // timing build: entry / exit stamps of the wave beside the loop's (loss_scene_loop)
             acc.d[0] = (float)(t_entry & 0xffffff);
             acc.d[1] = (float)(wall_clock64() & 0xffffff);
-            if (G > 1) {                // every wave of a scene-split workgroup reports its own loop stamps: planes 3 grp ..
-                const PlaneBuf pb = plane_buf(grad_input + (size_t)b * 12 * plane, 12, plane, pix);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) plane_store(pb, 3 * grp + k, acc.n[k]);
-            }
         }
 #endif
-        if (WITH_GRAD && G == 1) store_pixel_grad<HEAD>(head, acc, grad_input, b, plane, pix, lsum);
+        if (WITH_GRAD) store_pixel_grad<HEAD>(head, acc, grad_input, b, plane, pix);
     }
-    if constexpr (G > 1) {
-        // combine the G partial results of every pixel in wave 0, in wave order
-        __shared__ float part[(G - 1) * 13 * 64];
-        if (grp != 0) {
-            float *__restrict__ q = part + (grp - 1) * 13 * 64 + lane;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                q[(0 + k) * 64] = acc.n[k]; q[(3 + k) * 64] = acc.d[k];
-                q[(6 + k) * 64] = acc.r[k]; q[(9 + k) * 64] = acc.s[k];
-            }
-            q[12 * 64] = lsum;
-        }
-        __syncthreads();
-        if (grp != 0) return;           // waves 1..G-1 are done; no barrier follows
-#pragma unroll
-        for (int w = 1; w < G; ++w) {
-            const float *__restrict__ q = part + (w - 1) * 13 * 64 + lane;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                acc.n[k] += q[(0 + k) * 64]; acc.d[k] += q[(3 + k) * 64];
-                acc.r[k] += q[(6 + k) * 64]; acc.s[k] += q[(9 + k) * 64];
-            }
-            lsum += q[12 * 64];
-        }
-        if (active && !SVBRDF_TIMING) store_pixel_grad<HEAD>(head, acc, grad_input, b, plane, pix, lsum);
-        if (!active) lsum = 0.0f;
-        lsum = wave_sum(lsum);
-        bool fin = false;
-        if (lane == 0) fin = loss_arrive(lsum, fixed_scale, ws);
-        if (__any(fin)) loss_finish(lane, ws, loss_out, loss_scale);
-    } else {
+    {
         __shared__ float wave_part[kLossThreads / 64];
         __shared__ int finisher;
         lsum = wave_sum(lsum);
@@ -1595,46 +1317,10 @@ __global__ SVBRDF_K3_ATTRS void k_rendering_loss_inl([[maybe_unused]] const Scen
                                                      float *__restrict__ loss_out, int S, int H, int W)
 {
     const float *__restrict__ rows = (const float *)__builtin_amdgcn_kernarg_segment_ptr();
-    rendering_loss_body<WITH_GRAD, WITH_L1, HEAD, 1, true>(input, target, rows, xrow, eps, inv_count, loss_scale,
+    rendering_loss_body<WITH_GRAD, WITH_L1, HEAD, true>(input, target, rows, xrow, eps, inv_count, loss_scale,
                                                            fixed_scale, l1, grad_input, ws, loss_out, S, H, W);
 }
 
-// Scene-split workgroups (rendering_loss_body with G > 1): 64 pixels x G waves, forward+adjoint only.  An experiment of
-// round 4 that LOST (profiles/r04_ab_split.txt, DESIGN.md section 4.4: the per-wave fixed work -- plane loads, prepare(),
-// the un-pipelined first geometry, the finalise -- is worth 0.75 renders, so three waves per pixel cost 15 % more issue
-// slots than they recover from the tail): compiled only with -DSVBRDF_K3_SPLIT_VARIANTS=1 (tools/build_variant.sh), where
-// SVBRDF_K3_SPLIT=2|3|4 in the environment selects the layout.
-#if SVBRDF_K3_SPLIT_VARIANTS
-#define SVBRDF_K3_SPLIT_ATTRS(G) __launch_bounds__(64 * (G)) __attribute__((amdgpu_waves_per_eu(SVBRDF_K3_MIN_WAVES, 8)))
-template <bool WITH_L1, bool HEAD, int G>
-__global__ SVBRDF_K3_SPLIT_ATTRS(G) void k_rendering_loss_split(const float *__restrict__ input,
-                                                                const float *__restrict__ target,
-                                                                const float *__restrict__ scenes,
-                                                                const float *__restrict__ xrow, float eps, float inv_count,
-                                                                double loss_scale, float fixed_scale, L1Params l1,
-                                                                float *__restrict__ grad_input,
-                                                                unsigned long long *__restrict__ ws,
-                                                                float *__restrict__ loss_out, int S, int H, int W)
-{
-    rendering_loss_body<true, WITH_L1, HEAD, G>(input, target, scenes, xrow, eps, inv_count, loss_scale, fixed_scale, l1,
-                                                grad_input, ws, loss_out, S, H, W);
-}
-
-template <bool WITH_L1, bool HEAD, int G>
-__global__ SVBRDF_K3_SPLIT_ATTRS(G) void k_rendering_loss_split_inl([[maybe_unused]] const SceneBlock table,
-                                                                    const float *__restrict__ input,
-                                                                    const float *__restrict__ target,
-                                                                    const float *__restrict__ xrow, float eps,
-                                                                    float inv_count, double loss_scale, float fixed_scale,
-                                                                    L1Params l1, float *__restrict__ grad_input,
-                                                                    unsigned long long *__restrict__ ws,
-                                                                    float *__restrict__ loss_out, int S, int H, int W)
-{
-    const float *__restrict__ rows = (const float *)__builtin_amdgcn_kernarg_segment_ptr();
-    rendering_loss_body<true, WITH_L1, HEAD, G>(input, target, rows, xrow, eps, inv_count, loss_scale, fixed_scale, l1,
-                                                grad_input, ws, loss_out, S, H, W);
-}
-#endif  // SVBRDF_K3_SPLIT_VARIANTS
 
 #if defined(SVBRDF_ISA_PROBE)
 // tests/test_isa_guard.py: dot3 alone, to check in the assembly that its products are not contracted into FMAs
@@ -1838,10 +1524,9 @@ namespace {
 
 // launches one K3 variant; `rows` = the host scene table for the by-value kernels (NULL: device table `scenes`).
 // WHICH selects the variants this translation unit instantiates: 0 = <G, L1=0, HEAD=0> only, 1 = the other three,
-// 2 = all four.  `split` > 1 (forward+adjoint only): the scene-split kernels with that many waves per 64-pixel block;
-// the caller sized `grid` for the layout it asks for.
+// 2 = all four.
 template <bool G, int WHICH>
-void launch_k3(int split, bool with_l1, bool head, const float *rows, dim3 grid, size_t lds_bytes, hipStream_t st,
+void launch_k3(bool with_l1, bool head, const float *rows, dim3 grid, size_t lds_bytes, hipStream_t st,
                const float *input, const float *target, const float *scenes, const float *xrow, float eps,
                float inv_count, double loss_scale, float fixed_scale, L1Params l1, float *grad_input,
                unsigned long long *ws, float *loss_out, int B, int S, int H, int W)
@@ -1857,21 +1542,8 @@ void launch_k3(int split, bool with_l1, bool head, const float *rows, dim3 grid,
             hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), lds_bytes, st, input, target, scenes, xrow, eps,    \
                                inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, S, H, W);      \
     } while (0)
-#if SVBRDF_K3_SPLIT_VARIANTS
-#define SVBRDF_LAUNCH_K3_SPLIT(L, HD)                                                                           \
-    if constexpr (G) {                                                                                          \
-        if (split == 2) { SVBRDF_LAUNCH_K3_AS((k_rendering_loss_split<L, HD, 2>), (k_rendering_loss_split_inl<L, HD, 2>), 128); break; } \
-        if (split == 3) { SVBRDF_LAUNCH_K3_AS((k_rendering_loss_split<L, HD, 3>), (k_rendering_loss_split_inl<L, HD, 3>), 192); break; } \
-        if (split == 4) { SVBRDF_LAUNCH_K3_AS((k_rendering_loss_split<L, HD, 4>), (k_rendering_loss_split_inl<L, HD, 4>), 256); break; } \
-    }
-#else
-#define SVBRDF_LAUNCH_K3_SPLIT(L, HD) (void)split;
-#endif
 #define SVBRDF_LAUNCH_K3(L, HD)                                                                                 \
-    do {                                                                                                        \
-        SVBRDF_LAUNCH_K3_SPLIT(L, HD)                                                                           \
-        SVBRDF_LAUNCH_K3_AS((k_rendering_loss<G, L, HD>), (k_rendering_loss_inl<G, L, HD>), kLossThreads);      \
-    } while (0)
+    SVBRDF_LAUNCH_K3_AS((k_rendering_loss<G, L, HD>), (k_rendering_loss_inl<G, L, HD>), kLossThreads)
     if constexpr (WHICH != 0) {
         if (head) { if (with_l1) SVBRDF_LAUNCH_K3(true, true); else SVBRDF_LAUNCH_K3(false, true); }
         else if (with_l1) SVBRDF_LAUNCH_K3(true, false);
@@ -1880,7 +1552,6 @@ void launch_k3(int split, bool with_l1, bool head, const float *rows, dim3 grid,
         if (!head && !with_l1) SVBRDF_LAUNCH_K3(false, false);
     }
 #undef SVBRDF_LAUNCH_K3
-#undef SVBRDF_LAUNCH_K3_SPLIT
 #undef SVBRDF_LAUNCH_K3_AS
 }
 
@@ -1888,7 +1559,7 @@ void launch_k3(int split, bool with_l1, bool head, const float *rows, dim3 grid,
 
 // the forward+adjoint variants live in their own translation units (see the top of this file)
 #define SVBRDF_K3_ADJOINT_ARGS                                                                                        \
-    int split, int with_l1, int head, const float *rows, unsigned gx, unsigned gy, size_t lds_bytes, void *stream,      \
+    int with_l1, int head, const float *rows, unsigned gx, unsigned gy, size_t lds_bytes, void *stream,                 \
         const float *input, const float *target, const float *scenes, const float *xrow, float eps, float inv_count,   \
         double loss_scale, float fixed_scale, float l1_sum_scale, float l1_grad_scale, float l1_eps, float *grad_input, \
         unsigned long long *ws, float *loss_out, int B, int S, int H, int W
@@ -1897,7 +1568,7 @@ extern "C" __attribute__((visibility("hidden"))) void svbrdf_internal_launch_k3_
 #if SVBRDF_TU_ADJOINT_PLAIN
 void svbrdf_internal_launch_k3_adjoint_plain(SVBRDF_K3_ADJOINT_ARGS)
 {
-    launch_k3<true, 0>(split, with_l1 != 0, head != 0, rows, dim3(gx, gy, 1), lds_bytes,
+    launch_k3<true, 0>(with_l1 != 0, head != 0, rows, dim3(gx, gy, 1), lds_bytes,
                        static_cast<hipStream_t>(stream), input, target, scenes, xrow, eps, inv_count, loss_scale, fixed_scale,
                        L1Params{l1_sum_scale, l1_grad_scale, l1_eps}, grad_input, ws, loss_out, B, S, H, W);
 }
@@ -1905,7 +1576,7 @@ void svbrdf_internal_launch_k3_adjoint_plain(SVBRDF_K3_ADJOINT_ARGS)
 #if SVBRDF_TU_ADJOINT_EXTRA
 void svbrdf_internal_launch_k3_adjoint_extra(SVBRDF_K3_ADJOINT_ARGS)
 {
-    launch_k3<true, 1>(split, with_l1 != 0, head != 0, rows, dim3(gx, gy, 1), lds_bytes,
+    launch_k3<true, 1>(with_l1 != 0, head != 0, rows, dim3(gx, gy, 1), lds_bytes,
                        static_cast<hipStream_t>(stream), input, target, scenes, xrow, eps, inv_count, loss_scale, fixed_scale,
                        L1Params{l1_sum_scale, l1_grad_scale, l1_eps}, grad_input, ws, loss_out, B, S, H, W);
 }
@@ -2048,26 +1719,6 @@ size_t svbrdf_rendering_loss_workspace_bytes(int B, int S, int H, int W)
     return (kLossSlots + 1) * sizeof(unsigned long long);   // sharded fixed-point accumulators + ticket
 }
 
-// Workgroup layout of a forward+adjoint loss launch: 1 = 256 pixels per workgroup, every thread all renders of its
-// pixel (the product); 2, 3, 4 = 64 pixels x that many waves sharing the renders of a pixel -- only in experiment builds
-// (-DSVBRDF_K3_SPLIT_VARIANTS=1), selected by SVBRDF_K3_SPLIT in the environment (read once).
-static int pick_loss_split([[maybe_unused]] int B, [[maybe_unused]] int S, [[maybe_unused]] long long plane)
-{
-#if SVBRDF_K3_SPLIT_VARIANTS
-    static const int forced = [] {
-        const char *e = std::getenv("SVBRDF_K3_SPLIT");
-        const int v = e ? std::atoi(e) : 1;
-        return (v < 1 || v > 4) ? 1 : v;
-    }();
-    int split = forced > S ? S : forced;       // a wave without renders would only pay the prologue
-    // four times the workgroups must still fit the arrival counters
-    if (split > 1 && (unsigned long long)((plane + 63) / 64) * (unsigned long long)B >= (1ULL << 16) * kLossSlots) split = 1;
-    return split;
-#else
-    return 1;
-#endif
-}
-
 static int loss_impl(const char *who, bool head, bool scenes_on_host, const float *input, const float *target,
                      const float *scenes, const float *xrow, float eps, float l1_weight, float eps_l1,
                      float *loss_out, float *grad_input, void *workspace, size_t workspace_bytes, int B, int S,
@@ -2088,11 +1739,7 @@ static int loss_impl(const char *who, bool head, bool scenes_on_host, const floa
     const long long plane = (long long)H * W;
     if (plane > (1LL << 25))
         return fail(SVBRDF_ERR_DIMS, "loss: H*W exceeds 2^25 (one item's 12 planes are addressed with 32-bit byte offsets)");
-    // workgroup layout of the forward+adjoint kernels: 256 pixels x all renders (split 1), or 64 pixels x `split` waves
-    // that share the renders of a pixel (rendering_loss_body)
-    const int split = grad_input ? pick_loss_split(B, S, plane) : 1;
-    const long long wg_pixels = split > 1 ? 64 : kLossThreads;
-    const dim3 grid((unsigned)((plane + wg_pixels - 1) / wg_pixels), (unsigned)B, 1);
+    const dim3 grid((unsigned)((plane + kLossThreads - 1) / kLossThreads), (unsigned)B, 1);    // 256 pixels per workgroup
     const double count = (double)B * S * 3.0 * (double)plane;
     const float inv_count = (float)(1.0 / count);
     unsigned long long *ws = static_cast<unsigned long long *>(workspace);
@@ -2113,10 +1760,10 @@ static int loss_impl(const char *who, bool head, bool scenes_on_host, const floa
     const float *rows = scenes_on_host ? scenes : nullptr;
     if (grad_input)
         (l1_weight != 0.0f || head ? svbrdf_internal_launch_k3_adjoint_extra : svbrdf_internal_launch_k3_adjoint_plain)(
-            split, l1_weight != 0.0f, head, rows, grid.x, grid.y, lds_bytes, stream, input, target, scenes, xrow, eps,
+            l1_weight != 0.0f, head, rows, grid.x, grid.y, lds_bytes, stream, input, target, scenes, xrow, eps,
             inv_count, loss_scale, fixed_scale, l1.sum_scale, l1.grad_scale, l1.eps, grad_input, ws, loss_out, B, S, H, W);
     else
-        launch_k3<false, 2>(1, l1_weight != 0.0f, head, rows, grid, lds_bytes, st, input, target, scenes, xrow, eps,
+        launch_k3<false, 2>(l1_weight != 0.0f, head, rows, grid, lds_bytes, st, input, target, scenes, xrow, eps,
                             inv_count, loss_scale, fixed_scale, l1, grad_input, ws, loss_out, B, S, H, W);
     return launch_status(who);
 }

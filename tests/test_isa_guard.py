@@ -11,7 +11,7 @@ kernel k_rendering_loss_inl<GRAD=1,L1=0,HEAD=0> (and, more loosely, the MixedLos
   * three-lobe (untied) scene loop: VALU and transcendental count, no scratch traffic
   * numerics contract: the products of the exact dot products on the coords -> NH path are never contracted into
     FMAs: every dot3 must appear as 3 v_mul + 2 v_add; checked on the stand-alone `svbrdf_isa_probe_dot3` kernel
-    (n.wo, n.wi and wo.h, which do not feed NH, are explicit FMAs since round 4: SVBRDF_FMA_VN_LN).
+    (n.wo, n.wi and wo.h, which do not feed NH, are explicit FMAs since round 4).
 """
 import os
 import re

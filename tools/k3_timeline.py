@@ -1,6 +1,6 @@
 """Occupancy over time of one K3 launch (config 2) from per-wave stamps of a -DSVBRDF_TIMING=1 build
-(SVBRDF_HIP_LIB=<that build>; with -DSVBRDF_K3_SPLIT_VARIANTS=1 and SVBRDF_K3_SPLIT=G in the environment: the
-scene-split layout, every wave of a workgroup reporting its own loop stamps).  Prints waves resident / inside the
+(SVBRDF_HIP_LIB=<that build>: `bash tools/build_variant.sh tim -DSVBRDF_TIMING=1`; the scene-split layouts this tool also
+read in round 4 left the source in round 5).  Prints waves resident / inside the
 scene loop per SIMD in 24 time bins, and where the first and last microseconds of the launch go."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ def maps(B, H, gen, tied=True):
 dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(1)
 B, H, S = int(os.environ.get("K3_B", "8")), 256, int(os.environ.get("K3_S", "9"))
-G = int(os.environ.get("SVBRDF_K3_SPLIT", "1"))
+G = 1      # waves sharing a pixel's renders (the scene-split experiment of round 4: always 1 now)
 inp, tgt = maps(B, H, gen).to(dev), maps(B, H, gen).to(dev)
 torch.manual_seed(0)
 table = environment.BatchSceneSampler(B, S // 3, S - S // 3).sample()
