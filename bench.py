@@ -195,6 +195,13 @@ def cpu_baseline(args, inp, tgt, table):
     return res
 
 
+def median_region_index(job_elapsed):
+    """index of the MEDIAN timed region (by the job's time = MAX over ranks of each region); with an even count the
+    slower of the two middle regions, so that `value` never reads better than half of the regions did"""
+    order = sorted(range(len(job_elapsed)), key=lambda k: job_elapsed[k])
+    return order[len(order) // 2]
+
+
 def replayed_counters(library, B, H, S, record_path=None):
     """Hardware-counter figures of the headline kernel (HBM bytes, VALU instructions per launch) are NOT measured in a
     bench run -- rocprofv3 --pmc needs its own passes (tools/collect_profiles.sh) -- but replayed from
@@ -606,7 +613,7 @@ def main():
         t = torch.tensor(local_elapsed, dtype=torch.float64, device=where)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)            # per region: the slowest rank's time
         job_elapsed = [float(v) for v in t.tolist()]
-    median_region = sorted(range(n_regions), key=lambda k: job_elapsed[k])[n_regions // 2]
+    median_region = median_region_index(job_elapsed)
     elapsed, last = job_elapsed[median_region], lasts[median_region]
     region_ms_per_launch = region_ms[median_region]
     if dist is not None:

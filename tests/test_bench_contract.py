@@ -61,3 +61,16 @@ def test_bench_source_emits_the_contract_keys():
                 "cpu_baseline", "cores", "kind", "sample", "per_gpu_value", "value_through_autograd_engine", "valu_issue_frac",
                 "all_cores_patches_per_s", "shader_cycles_per_launch", "valu_issue_frac"):
         assert '"%s"' % key in src, key
+
+
+def test_short_form_reports_the_median_region():
+    """bench.py's short forms time >= 9 regions and report the median one"""
+    import bench
+    assert bench.median_region_index([3.0]) == 0
+    assert bench.median_region_index([5.0, 1.0, 3.0]) == 2
+    t = [0.80, 0.76, 0.79, 0.77, 0.95, 0.78, 0.76, 0.81, 0.77]            # one outlier region
+    assert t[bench.median_region_index(t)] == 0.78
+    assert bench.median_region_index([1.0, 2.0, 3.0, 4.0]) == 2             # even count: the slower middle one
+    with open(os.path.join(ROOT, "bench.py")) as f:
+        src = f.read()
+    assert "n_regions = 1 if args.steps >= 256 else max(9, args.regions)" in src
