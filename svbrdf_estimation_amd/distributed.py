@@ -68,6 +68,11 @@ def global_mean(local_mean):
 BRINGUP_EXIT_CODE = 3
 
 
+class ProcessGroupBringupError(RuntimeError):
+    """the process group did not come up (rendezvous, communicator set-up or the first collective raised, or the group is
+    not the size the launcher said); the message is the multi-line diagnosis of ``bringup_diagnosis``"""
+
+
 def bringup_diagnosis(backend, device, phase, waited_s):
     """what a maintainer needs to see when the process group does not come up (one line per fact, for stderr)"""
     import os
@@ -133,17 +138,34 @@ class _BringupWatchdog:
             pass
 
 
-def init_process_group_checked(backend, device=None, timeout_s=60.0):
+def init_process_group_checked(backend, device=None, timeout_s=60.0, exit_on_failure=True):
     """``dist.init_process_group`` + ONE one-element all-reduce (the first collective is where RCCL builds its
-    communicator, opens its IPC handles and its xGMI rings), under a watchdog: if both have not completed within
-    `timeout_s` seconds, or either raises, the diagnosis goes to stderr and the process exits with BRINGUP_EXIT_CODE
-    (launch.spawn_ranks / torchrun then stop the other ranks).  Returns ``ranks_seen`` = the sum of ones over the group
-    -- counted by the collective itself, not read from the environment.  `device`: this rank's torch.device for
-    backend "nccl" (passed as device_id: eager communicator on that device), ignored for gloo."""
+    communicator, opens its IPC handles and its xGMI rings), under a watchdog.  Returns ``ranks_seen`` = the sum of ones
+    over the group -- counted by the collective itself, not read from the environment.
+
+    Failure modes.  (a) Nothing completes within `timeout_s` seconds (a peer that never arrives, RCCL wedged in its
+    set-up): the thread that called this is blocked inside torch and cannot be interrupted, so the watchdog prints the
+    diagnosis and ends the PROCESS with BRINGUP_EXIT_CODE -- always; launch.spawn_ranks / torchrun then stop the other
+    ranks.  (b) Something raises, or the group is not the size the launcher said: with `exit_on_failure` (what bench.py
+    and train.py use: a rank's half-built communicator must not get a chance to hang in a destructor) the diagnosis is
+    printed and the process exits with BRINGUP_EXIT_CODE; otherwise ``ProcessGroupBringupError`` carries the diagnosis to
+    the caller.  `device`: this rank's torch.device for backend "nccl" (passed as device_id: eager communicator on that
+    device), ignored for gloo."""
     import os
     import sys
     import torch.distributed as dist
     nccl = backend == "nccl"
+
+    def failed(text, cause=None):
+        if exit_on_failure:
+            if cause is not None:
+                import traceback
+                traceback.print_exception(type(cause), cause, cause.__traceback__)
+            sys.stderr.write(text + "\n")
+            sys.stderr.flush()
+            os._exit(BRINGUP_EXIT_CODE)         # not sys.exit: no destructor of a half-built communicator gets to hang
+        raise ProcessGroupBringupError(text) from cause
+
     wd = _BringupWatchdog(timeout_s, backend, device).start()
     try:
         wd.phase = "the rendezvous / communicator set-up (init_process_group)"
@@ -152,19 +174,14 @@ def init_process_group_checked(backend, device=None, timeout_s=60.0):
         one = torch.ones(1, dtype=torch.float32, device=device if nccl else "cpu")
         dist.all_reduce(one, op=dist.ReduceOp.SUM)
         seen = int(round(float(one.item())))            # .item(): the reduction has really finished
+    except (KeyboardInterrupt, SystemExit):
+        wd.cancel()
+        raise
     except BaseException as e:
         wd.cancel()
-        if isinstance(e, (KeyboardInterrupt, SystemExit)):
-            raise
-        import traceback
-        traceback.print_exc()
-        sys.stderr.write(bringup_diagnosis(backend, device, wd.phase + " -- raised %r" % (e,), 0.0) + "\n")
-        sys.stderr.flush()
-        os._exit(BRINGUP_EXIT_CODE)         # not sys.exit: no destructor of a half-built communicator gets to hang
+        failed(bringup_diagnosis(backend, device, wd.phase + " -- raised %r" % (e,), 0.0), e)
     wd.cancel()
     if seen != dist.get_world_size():
-        sys.stderr.write(bringup_diagnosis(backend, device, "the first collective -- it summed %d ones over a group of %d"
-                                           % (seen, dist.get_world_size()), 0.0) + "\n")
-        sys.stderr.flush()
-        os._exit(BRINGUP_EXIT_CODE)
+        failed(bringup_diagnosis(backend, device, "the first collective -- it summed %d ones over a group of %d"
+                                 % (seen, dist.get_world_size()), 0.0))
     return seen

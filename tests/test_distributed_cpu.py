@@ -199,6 +199,21 @@ def test_bring_up_error_is_a_diagnosis_not_a_bare_traceback():
     assert "[bring-up] rank 1 of 2" in r.stderr and "no-such-host.invalid:29999" in r.stderr
 
 
+def test_bring_up_error_can_be_an_exception_for_library_callers():
+    """exit_on_failure=False: a caller that is not a rank script gets ProcessGroupBringupError with the diagnosis"""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "os.environ.update(RANK='1', WORLD_SIZE='2', MASTER_ADDR='no-such-host.invalid', MASTER_PORT='29998')\n"
+            "from svbrdf_estimation_amd import distributed as D\n"
+            "try:\n"
+            "    D.init_process_group_checked('gloo', None, 30.0, exit_on_failure=False)\n"
+            "except D.ProcessGroupBringupError as e:\n"
+            "    assert 'no-such-host.invalid:29998' in str(e) and e.__cause__ is not None\n"
+            "    print('RAISED')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=_clean_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "RAISED" in r.stdout, (r.returncode, r.stdout, r.stderr[-1500:])
+
+
 def test_bench_refuses_a_world_that_is_not_gpus():
     """a launcher environment whose WORLD_SIZE contradicts --gpus must be an error, not a silent 1-rank run"""
     import subprocess
