@@ -200,18 +200,23 @@ def test_bring_up_error_is_a_diagnosis_not_a_bare_traceback():
 
 
 def test_bring_up_error_can_be_an_exception_for_library_callers():
-    """exit_on_failure=False: a caller that is not a rank script gets ProcessGroupBringupError with the diagnosis"""
+    """exit_on_failure=False: a caller that is not a rank script gets ProcessGroupBringupError with the diagnosis and the
+    original exception as its cause (here: a backend torch does not know -- raised at once, inside the watchdog's window)"""
     import subprocess
     code = ("import os, sys; sys.path.insert(0, %r)\n"
-            "os.environ.update(RANK='1', WORLD_SIZE='2', MASTER_ADDR='no-such-host.invalid', MASTER_PORT='29998')\n"
+            "os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29997')\n"
             "from svbrdf_estimation_amd import distributed as D\n"
             "try:\n"
-            "    D.init_process_group_checked('gloo', None, 30.0, exit_on_failure=False)\n"
+            "    D.init_process_group_checked('no-such-backend', None, 30.0, exit_on_failure=False)\n"
             "except D.ProcessGroupBringupError as e:\n"
-            "    assert 'no-such-host.invalid:29998' in str(e) and e.__cause__ is not None\n"
+            "    assert '127.0.0.1:29997' in str(e) and 'no-such-backend' in str(e) and e.__cause__ is not None\n"
             "    print('RAISED')\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code], env=_clean_env(), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "RAISED" in r.stdout, (r.returncode, r.stdout, r.stderr[-1500:])
+    # ... and the rank scripts' mode: same failure, diagnosis on stderr, exit code 3
+    r = subprocess.run([sys.executable, "-c", code.replace("exit_on_failure=False", "exit_on_failure=True")], env=_clean_env(),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "[bring-up] rank 0 of 1" in r.stderr and "RAISED" not in r.stdout, (r.returncode, r.stderr[-800:])
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():
