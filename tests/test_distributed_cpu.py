@@ -188,7 +188,8 @@ def test_bring_up_fails_fast_with_a_diagnosis_when_a_rank_never_arrives():
 
 
 def test_bring_up_error_is_a_diagnosis_not_a_bare_traceback():
-    """the other failure mode: the rendezvous raises at once (an address that does not resolve) -> same diagnosis, code 3"""
+    """a rendezvous address that does not resolve: torch's store client keeps retrying (minutes), so it is again the
+    watchdog that ends the rank after --bringup-timeout -- same diagnosis, code 3"""
     import subprocess
     env = _clean_env()
     env.update(RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="no-such-host.invalid",
