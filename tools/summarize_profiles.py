@@ -26,6 +26,25 @@ def one(pattern):
 st = one("%s_stats/*/*_kernel_stats.csv" % tag)
 if st:
     shutil.copy(st, os.path.join(P, "%s_kernel_stats.csv" % tag))                 # default command: two streams
+if st:
+    # The verbatim summary averages EVERY launch of the fused loss in the process -- including those of bench.py's untimed
+    # follow-up leg that alternates steps on two streams, where two launches overlap and each reads ~70 us.  The per-dispatch
+    # trace of the same pass, split by the stream a launch ran on: the launch stream of the timed region on its own line.
+    tr = st.replace("_kernel_stats.csv", "_kernel_trace.csv")
+    if os.path.exists(tr):
+        by = collections.defaultdict(list)
+        for r in csv.DictReader(open(tr)):
+            if "k_rendering_loss" in r["Kernel_Name"]:
+                by[(r["Queue_Id"], r["Stream_Id"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        with open(os.path.join(P, "%s_kernel_stats_by_stream.csv" % tag), "w") as f:
+            f.write('"Kernel","Queue_Id","Stream_Id","Calls","AverageNs","MinNs","MaxNs","Note"\n')
+            main = max(by, key=lambda k: len(by[k])) if by else None
+            for k in sorted(by, key=lambda k: -len(by[k])):
+                v = by[k]
+                f.write('"k_rendering_loss*",%s,%s,%d,%.1f,%d,%d,"%s"\n' % (
+                    k[0], k[1], len(v), sum(v) / len(v), min(v), max(v),
+                    "the launch stream of the timed region: one launch at a time" if k == main else
+                    "a stream of the untimed two-stream follow-up leg: launches overlap"))
 st1 = one("%s_stats1/*/*_kernel_stats.csv" % tag)
 if st1:
     shutil.copy(st1, os.path.join(P, "%s_kernel_stats_streams1.csv" % tag))      # round 2 layout: --streams 1 beside a two-stream default
@@ -75,7 +94,12 @@ if k3 and "FETCH_SIZE" in summary[k3] and "WRITE_SIZE" in summary[k3]:
     for key, counter in (("valu_wave_instr_per_launch", "SQ_INSTS_VALU"), ("trans_wave_instr_per_launch", "SQ_INSTS_VALU_TRANS_F32")):
         if counter in summary[k3]:
             traffic[key] = summary[k3][counter]["mean"]
-    json.dump(traffic, open(os.path.join(P, "k3_hbm_traffic.json"), "w"), indent=1)
+    prev_path = os.path.join(P, "k3_hbm_traffic.json")
+    if os.path.exists(prev_path):       # re-summarising the same recording later must not re-date it
+        prev = json.load(open(prev_path))
+        if all(prev.get(k) == traffic.get(k) for k in ("FETCH_SIZE_KiB_raw", "WRITE_SIZE_KiB_raw", "valu_wave_instr_per_launch", "kernel_code_sha256")):
+            traffic["git_head"] = prev.get("git_head", traffic["git_head"])
+    json.dump(traffic, open(prev_path, "w"), indent=1)
     summary["_k3_traffic"] = traffic
 json.dump(summary, open(os.path.join(P, "%s_pmc_summary.json" % tag), "w"), indent=1, sort_keys=True)
 # ---- the other kernels / K3 variants (tools/kernel_cases.py, one process per case and pass)
