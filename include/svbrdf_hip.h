@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SVBRDF_ABI_VERSION 6
+#define SVBRDF_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define SVBRDF_API __attribute__((visibility("default")))
@@ -198,6 +198,38 @@ SVBRDF_API int svbrdf_debug_check_arith(unsigned long long n, unsigned seed, flo
  *   operation order and roundings as the reference.  H and W are independent here.  `out` may not alias the inputs. */
 SVBRDF_API int svbrdf_mix_materials(const float *svbrdf0, const float *svbrdf1, const float *alpha, float *out,
                                     int B, int H, int W, void *stream);
+
+/* K1 with the sensor-noise epilogue (ABI version 7) -- replaces the loop body of SvbrdfDataset.render_inputs
+ * (dataset.py:206-219: render, + N(0, std_image) from the CPU generator, torch.clamp(0, 1)) for a whole batch of samples
+ * and all their photos in ONE launch that writes each photo once:
+ *   out[b,s] = clamp(render(scene[b,s], maps[b]) + noise_std[b,s] * n(seed, offset, element), 0, 1)     [B,S,3,H,W]
+ * `noise_std` holds one level per render ([B*S], the reference draws it per image, dataset.py:215); NULL = no noise,
+ * clamp only: bitwise clamp(svbrdf_render_fwd(...)).  The standard-normal field n is counter-based and a pure function of
+ * (seed, offset, linear index e of the element in `out`): Philox4x32-10 with key = (seed lo, seed hi) and counter =
+ * (g lo, g hi, offset lo, offset hi), g = e / 4, gives four 32-bit words x0..x3; u_i = ((x_i >> 8) + 0.5) / 2^24;
+ * n(4g) = r(u0) cos(2 pi u1), n(4g+1) = r(u0) sin(2 pi u1), n(4g+2) = r(u2) cos(2 pi u3), n(4g+3) = r(u2) sin(2 pi u3),
+ * r(u) = sqrt(-2 ln u).  The field does not depend on the vector width of the launch; a caller advances `offset` (or the
+ * seed) between calls, like a device generator.  Different numbers than the reference's CPU field, the same distribution.
+ * `svbrdf_render_inputs`: scenes and levels are DEVICE tables.  `_host_scenes`: both are HOST arrays of B*S rows
+ * (<= SVBRDF_HOST_SCENES_MAX_ROWS) that travel by value in the launch's argument block, as in
+ * svbrdf_render_fwd_host_scenes (one scene table row per render; not shared between maps: every sample draws its own
+ * views, dataset.py:172-204). */
+SVBRDF_API int svbrdf_render_inputs(const float *maps, const float *scenes, const float *noise_std, unsigned long long seed,
+                                    unsigned long long offset, const float *xrow, float *out, int B, int S, int H, int W,
+                                    void *stream);
+SVBRDF_API int svbrdf_render_inputs_host_scenes(const float *maps, const float *scenes_host, const float *noise_std_host,
+                                                unsigned long long seed, unsigned long long offset, const float *xrow,
+                                                float *out, int B, int S, int H, int W, void *stream);
+
+/* Measurement aid (ABI version 7): dst[i] = src[i] for i < n floats (n a multiple of 4, both pointers 16-byte aligned,
+ * no overlap) as a plain streaming copy, 16 bytes per lane and access, non-temporal loads and stores.  bench.py and the
+ * speed guard time it on buffers beyond the Infinity Cache: 2 * 4 * n bytes / duration is the copy bandwidth of THIS
+ * box, the "measured-copy peak" the HBM-bound kernels are priced against beside the nominal 8 TB/s. */
+SVBRDF_API int svbrdf_debug_copy(float *dst, const float *src, size_t n, void *stream);
+
+/* Test aid (ABI version 7): how many kernels this library has enqueued in this process (every entry point enqueues
+ * exactly one; failed calls are not counted).  tests/test_gpu_perf_guard.py asserts ONE launch per training step. */
+SVBRDF_API unsigned long long svbrdf_debug_launch_count(void);
 
 /* Measurement aid: one wave spins for `ticks_100mhz` ticks of the chip's constant 100 MHz counter on `stream`
  * and writes out_dev[0] = shader-clock cycles elapsed, out_dev[1] = 100 MHz ticks elapsed (two device uint64).

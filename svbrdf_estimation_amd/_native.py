@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SVBRDF_HIP_LIB: load another build of the same ABI (ablation/experiment builds of tools/); default in-tree
 _SO = os.environ.get("SVBRDF_HIP_LIB") or os.path.join(_HERE, "lib", "libsvbrdf_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lock = threading.Lock()
 _lib = None
@@ -91,6 +91,13 @@ def _load():
         lib.svbrdf_render_fwd_f64.restype = lib.svbrdf_render_bwd_f64.restype = ctypes.c_int
         lib.svbrdf_render_bwd_jvp_f64.argtypes = [_fp] * 7 + [ctypes.c_int] * 4 + [_fp]
         lib.svbrdf_render_bwd_jvp_f64.restype = ctypes.c_int
+        lib.svbrdf_render_inputs.argtypes = [_fp, _fp, _fp, ctypes.c_ulonglong, ctypes.c_ulonglong, _fp, _fp] + [ctypes.c_int] * 4 + [_fp]
+        lib.svbrdf_render_inputs_host_scenes.argtypes = lib.svbrdf_render_inputs.argtypes
+        lib.svbrdf_render_inputs.restype = lib.svbrdf_render_inputs_host_scenes.restype = ctypes.c_int
+        lib.svbrdf_debug_copy.argtypes = [_fp, _fp, ctypes.c_size_t, _fp]
+        lib.svbrdf_debug_copy.restype = ctypes.c_int
+        lib.svbrdf_debug_launch_count.argtypes = []
+        lib.svbrdf_debug_launch_count.restype = ctypes.c_ulonglong
         v = lib.svbrdf_abi_version()
         if v != ABI_VERSION:
             raise NativeLibraryError("ABI mismatch: library %d, binding %d -- rebuild" % (v, ABI_VERSION))
@@ -291,6 +298,73 @@ def render_fwd(maps, scenes):
             _check(lib.svbrdf_render_fwd(maps.data_ptr(), table.data_ptr(), xrow(maps.device, W).data_ptr(),
                                          out.data_ptr(), B, S, H, W, _stream(maps.device)), "svbrdf_render_fwd")
     return out
+
+
+def device_philox_state(device, generator=None):
+    """(seed, offset) for one launch of a counter-based noise kernel, taken from -- and advancing -- torch's generator of
+    `device` the way torch's own device random ops do: ``torch.cuda.manual_seed`` therefore controls the sensor noise of
+    ``render_inputs`` like it controls ``torch.randn(..., device=...)``.  The kernel uses the offset as the upper counter
+    words, so advancing it by one unit (4, the granularity torch requires) gives the next launch a disjoint counter space."""
+    gen = generator if generator is not None else torch.cuda.default_generators[
+        device.index if device.index is not None else torch.cuda.current_device()]
+    seed, offset = int(gen.initial_seed()), int(gen.get_offset())
+    gen.set_offset(offset + 4)
+    return seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF
+
+
+def render_inputs(maps, scenes, noise_std=None, seed=0, offset=0):
+    """K1 + sensor-noise epilogue (svbrdf_render_inputs*): maps [B,12,H,W] device; scenes [B,S,9] and noise_std [B,S]
+    (or None: clamp only) BOTH on the host (at most host_scenes_max_rows() rows: they ride in the launch's argument block)
+    or both on the maps' device -> clamp(render + noise_std * N(0,1), 0, 1) [B,S,3,H,W], ONE launch, each photo written
+    once.  The normal field is a pure function of (seed, offset, element index): see include/svbrdf_hip.h."""
+    _require_device_f32(maps, "maps")
+    if not maps.is_contiguous():
+        maps = maps.contiguous()
+    B, S, H, W, shared = _dims(maps, scenes)
+    if shared:
+        raise ValueError("render_inputs needs one scene row per photo: scenes must be [B,S,9]")
+    if scenes.dtype != torch.float32:
+        raise TypeError("scenes must be float32 (got %s)" % scenes.dtype)
+    if noise_std is not None:
+        if not isinstance(noise_std, torch.Tensor) or noise_std.dtype != torch.float32 or noise_std.numel() != B * S:
+            raise ValueError("noise_std must be a float32 tensor of B*S = %d levels" % (B * S))
+        if noise_std.is_cuda != scenes.is_cuda:
+            raise ValueError("scenes and noise_std must both be on the host or both on the maps' device")
+    on_host = not scenes.is_cuda
+    if on_host and B * S > host_scenes_max_rows():
+        scenes = upload_scene_table(scenes, maps.device)
+        noise_std = upload_scene_table(noise_std.reshape(-1), maps.device) if noise_std is not None else None
+        on_host = False
+    if not on_host and (scenes.device != maps.device or (noise_std is not None and noise_std.device != maps.device)):
+        raise ValueError("device scene / noise tables must live with the maps")
+    scenes = scenes.contiguous()
+    sig = noise_std.contiguous() if noise_std is not None else None
+    out = torch.empty((B, S, 3, H, W), dtype=torch.float32, device=maps.device)
+    lib = _load()
+    fn = lib.svbrdf_render_inputs_host_scenes if on_host else lib.svbrdf_render_inputs
+    with _on_device(maps.device):
+        _check(fn(maps.data_ptr(), scenes.data_ptr(), sig.data_ptr() if sig is not None else None,
+                  ctypes.c_ulonglong(int(seed) & 0xFFFFFFFFFFFFFFFF), ctypes.c_ulonglong(int(offset) & 0xFFFFFFFFFFFFFFFF),
+                  xrow(maps.device, W).data_ptr(), out.data_ptr(), B, S, H, W, _stream(maps.device)),
+               "svbrdf_render_inputs_host_scenes" if on_host else "svbrdf_render_inputs")
+    return out
+
+
+def debug_copy(dst, src):
+    """svbrdf_debug_copy: dst[:] = src as a streaming float4 copy kernel on the current stream (measurement aid: the copy
+    bandwidth of this box, bench.py / tests/test_gpu_perf_guard.py)"""
+    _require_device_f32(dst, "dst")
+    _require_device_f32(src, "src")
+    if dst.numel() != src.numel() or not dst.is_contiguous() or not src.is_contiguous() or dst.device != src.device:
+        raise ValueError("debug_copy needs two contiguous tensors of one size on one device")
+    with _on_device(dst.device):
+        _check(_load().svbrdf_debug_copy(dst.data_ptr(), src.data_ptr(), dst.numel(), _stream(dst.device)), "svbrdf_debug_copy")
+    return dst
+
+
+def launch_count():
+    """kernels enqueued by libsvbrdf_hip.so in this process so far (svbrdf_debug_launch_count)"""
+    return int(_load().svbrdf_debug_launch_count())
 
 
 def render_bwd(maps, scenes, grad_out):

@@ -31,6 +31,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -550,12 +551,97 @@ struct SceneBlock {
 };
 
 // ------------------------------------------------------------------------------------------
+// Sensor-noise epilogue of the input-photo synthesis (dataset.py:215-217: rendering + N(0, sigma_image), clamp [0,1]),
+// fused into K1's store.  The reference draws the field from torch's CPU generator; here it is counter-based:
+// Philox4x32-10 (Salmon et al., SC'11; the generator behind torch's device randn) keyed with the caller's 64-bit seed,
+// counter = (group index lo, hi, offset lo, hi) where group = linear index of the OUTPUT element / 4.  One call gives four
+// uniforms -> two Box-Muller pairs -> the four normals of elements 4g .. 4g+3, so the field is a pure function of
+// (seed, offset, element index): independent of the vector width the launch picked, reproducible, and a VEC = 4 lane
+// (four adjacent pixels of one plane row, 16-byte aligned) spends exactly one Philox call per plane it stores.
+// ------------------------------------------------------------------------------------------
+struct PhiloxKey {
+    unsigned k0, k1;        // seed
+    unsigned c2, c3;        // offset (upper counter words)
+};
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned out[4])
+{
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// four standard normals of output-element group g: u = (top 24 bits + 0.5) / 2^24 in (0,1);
+// (n0, n1) = sqrt(-2 ln u0) (cos, sin)(2 pi u1), (n2, n3) likewise from u2, u3.  v_sin/v_cos take revolutions.
+[[maybe_unused]] __device__ __forceinline__ void normal4(const PhiloxKey &key, unsigned long long g, float n[4])
+{
+    unsigned r[4];
+    philox4x32_10((unsigned)g, (unsigned)(g >> 32), key.c2, key.c3, key.k0, key.k1, r);
+    constexpr float kInv24 = 1.0f / 16777216.0f;
+    constexpr float kM2Ln2 = -1.38629436111989061883f;      // -2 ln 2: -2 ln u = kM2Ln2 * log2 u
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u0 = fma_((float)(r[2 * h] >> 8), kInv24, 0.5f * kInv24);
+        const float u1 = fma_((float)(r[2 * h + 1] >> 8), kInv24, 0.5f * kInv24);
+        const float rad = __builtin_amdgcn_sqrtf(kM2Ln2 * log2_(u0));
+        n[2 * h] = rad * __builtin_amdgcn_cosf(u1);
+        n[2 * h + 1] = rad * __builtin_amdgcn_sinf(u1);
+    }
+}
+
+// EPI: what happens to a radiance on its way to memory.  0 = stored as computed (LocalRenderer.render);
+// 1 = clamp to [0,1]; 2 = + sigma[render] * N(0,1), then clamp to [0,1] (render_inputs, dataset.py:215-217)
+struct Epilogue {
+    const float *__restrict__ sigma;    // per render, wave-uniform (device table or kernel-argument block)
+    PhiloxKey key;
+};
+
+// `elem` = linear index in `out` of t[0].  A lane's VEC values are adjacent elements of one plane row starting at a multiple
+// of VEC, and a plane holds H*W = W*W elements with W a multiple of VEC (pick_vec), so they always share ONE group of four:
+// one Philox call per lane and stored plane whatever the width.
+template <int VEC, int EPI>
+__device__ __forceinline__ void finish_radiance(const Epilogue &ep, float sig, unsigned long long elem, float t[VEC])
+{
+    if constexpr (EPI == 2) {
+        float n[4];
+        normal4(ep.key, elem >> 2, n);
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) t[v] = fma_(sig, n[v], t[v]);
+        } else if constexpr (VEC == 2) {
+            const bool upper = (elem & 2ull) != 0;
+            t[0] = fma_(sig, upper ? n[2] : n[0], t[0]);
+            t[1] = fma_(sig, upper ? n[3] : n[1], t[1]);
+        } else {
+            const unsigned lane = (unsigned)elem & 3u;
+            const float lo = (lane & 1u) ? n[1] : n[0], hi = (lane & 1u) ? n[3] : n[2];
+            t[0] = fma_(sig, (lane & 2u) ? hi : lo, t[0]);
+        }
+    }
+    if constexpr (EPI != 0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) t[v] = t[v] < 0.0f ? 0.0f : (t[v] > 1.0f ? 1.0f : t[v]);   // torch.clamp(min=0, max=1): a NaN stays a NaN
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K1: render forward.  grid = (ceil(H*W / (256*VEC)), B); S renders per map in one pass.
 // ------------------------------------------------------------------------------------------
-template <int VEC, int NL>
+template <int VEC, int NL, int EPI = 0>
 __device__ __forceinline__ void render_fwd_loop(const MapK mk[VEC], const float x[VEC], float y,
                                                 const float *__restrict__ scp, float *__restrict__ o,
-                                                size_t plane, int S)
+                                                size_t plane, int S, [[maybe_unused]] const Epilogue &ep,
+                                                [[maybe_unused]] unsigned long long elem)
 {
     const VConst K = make_vconst();
     for (int s = 0; s < S; ++s, scp += 9, o += 3 * plane) {
@@ -570,11 +656,14 @@ __device__ __forceinline__ void render_fwd_loop(const MapK mk[VEC], const float 
             float F[3], f[3];
             shade<NL, false>(K, g, mk[v], d, lb, F, f, rad[v]);
         }
+        [[maybe_unused]] float sig = 0.0f;
+        if constexpr (EPI == 2) sig = ep.sigma[s];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             float t[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) t[v] = rad[v][k];
+            if constexpr (EPI != 0) finish_radiance<VEC, EPI>(ep, sig, elem + (unsigned long long)(3 * s + k) * plane, t);
             store_vec<VEC>(o + (size_t)k * plane, t);
         }
     }
@@ -584,10 +673,11 @@ __device__ __forceinline__ void render_fwd_loop(const MapK mk[VEC], const float 
 // (any number per map, zero included) instead of the regular S per map.  `shared`: ONE list of S scenes for every
 // map (rows 0 .. S-1 of `scenes`) instead of S rows per map -- LocalRenderer.render's "one scene, B maps"
 // (renderers.py:98) without materialising B copies of the row.
-template <int VEC>
+template <int VEC, int EPI = 0>
 __device__ __forceinline__ void render_fwd_body(const float *__restrict__ maps, const float *__restrict__ scenes,
                                                 const float *__restrict__ xrow, float *__restrict__ out,
-                                                const int *__restrict__ offsets, bool shared, int S, int H, int W)
+                                                const int *__restrict__ offsets, bool shared, int S, int H, int W,
+                                                Epilogue ep = Epilogue{nullptr, PhiloxKey{0, 0, 0, 0}})
 {
     const size_t plane = (size_t)H * W;
     const size_t pix = ((size_t)blockIdx.x * kThreads + threadIdx.x) * VEC;
@@ -613,8 +703,10 @@ __device__ __forceinline__ void render_fwd_body(const float *__restrict__ maps, 
     }
     const float *__restrict__ scp = scenes + (shared ? 0 : first * 9);
     float *__restrict__ o = out + first * 3 * plane + pix;
-    if (__all(tied)) render_fwd_loop<VEC, 1>(mk, x, y, scp, o, plane, S);      // wave-uniform branch
-    else render_fwd_loop<VEC, 3>(mk, x, y, scp, o, plane, S);
+    const unsigned long long elem = (unsigned long long)first * 3ull * plane + pix;    // linear index of o[0] in `out`
+    if constexpr (EPI == 2) ep.sigma += first;                                 // one noise level per render, like the scenes
+    if (__all(tied)) render_fwd_loop<VEC, 1, EPI>(mk, x, y, scp, o, plane, S, ep, elem);      // wave-uniform branch
+    else render_fwd_loop<VEC, 3, EPI>(mk, x, y, scp, o, plane, S, ep, elem);
 }
 
 template <int VEC>
@@ -639,6 +731,34 @@ __global__ __launch_bounds__(kThreads) void k_render_fwd_inl([[maybe_unused]] co
 {
     const float *__restrict__ rows = (const float *)__builtin_amdgcn_kernarg_segment_ptr();
     render_fwd_body<VEC>(maps, rows, xrow, out, nullptr, shared != 0, S, H, W);
+}
+
+// K1 with the sensor-noise epilogue (render_inputs, dataset.py:206-219): EPI = 1 clamp, 2 noise + clamp.  The noise levels
+// (one per render) come from a device table, or ride behind the scene rows in the argument block.
+struct PhotoBlock {
+    float v[SVBRDF_HOST_SCENES_MAX_ROWS * 9];
+    float sigma[SVBRDF_HOST_SCENES_MAX_ROWS];
+};
+
+template <int VEC, int EPI>
+__global__ __launch_bounds__(kThreads) void k_render_inputs(const float *__restrict__ maps,
+                                                            const float *__restrict__ scenes,
+                                                            const float *__restrict__ sigma, PhiloxKey key,
+                                                            const float *__restrict__ xrow, float *__restrict__ out,
+                                                            int S, int H, int W)
+{
+    render_fwd_body<VEC, EPI>(maps, scenes, xrow, out, nullptr, false, S, H, W, Epilogue{sigma, key});
+}
+
+template <int VEC, int EPI>
+__global__ __launch_bounds__(kThreads) void k_render_inputs_inl([[maybe_unused]] const PhotoBlock table, PhiloxKey key,
+                                                                const float *__restrict__ maps,
+                                                                const float *__restrict__ xrow, float *__restrict__ out,
+                                                                int S, int H, int W)
+{
+    const float *__restrict__ rows = (const float *)__builtin_amdgcn_kernarg_segment_ptr();
+    render_fwd_body<VEC, EPI>(maps, rows, xrow, out, nullptr, false, S, H, W,
+                              Epilogue{rows + SVBRDF_HOST_SCENES_MAX_ROWS * 9, key});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1441,6 +1561,28 @@ __global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *__restri
     out[1] = r1 - r0;
 }
 
+// ------------------------------------------------------------------------------------------
+// measurement aid: the HBM copy rate of THIS box ("fraction of both nominal and measured-copy peak").  A plain
+// streaming copy, 16 bytes per lane and access, non-temporal both ways, kCopyUnroll independent loads in flight per lane
+// before the first store; a workgroup owns one contiguous 16 KiB chunk.  Bytes moved = 2 x n x 4.
+// ------------------------------------------------------------------------------------------
+constexpr int kCopyUnroll = 4;
+__global__ __launch_bounds__(kThreads) void k_copy_vec4(vec4f *__restrict__ dst, const vec4f *__restrict__ src, size_t n4)
+{
+    const size_t base = (size_t)blockIdx.x * (kThreads * kCopyUnroll) + threadIdx.x;
+    vec4f v[kCopyUnroll];
+#pragma unroll
+    for (int u = 0; u < kCopyUnroll; ++u) {
+        const size_t i = base + (size_t)u * kThreads;
+        if (i < n4) v[u] = __builtin_nontemporal_load(src + i);
+    }
+#pragma unroll
+    for (int u = 0; u < kCopyUnroll; ++u) {
+        const size_t i = base + (size_t)u * kThreads;
+        if (i < n4) __builtin_nontemporal_store(v[u], dst + i);
+    }
+}
+
 #endif  // SVBRDF_TU_MAIN (kernels)
 
 }  // namespace
@@ -1456,6 +1598,7 @@ extern "C" __attribute__((visibility("hidden"))) int svbrdf_internal_launch_stat
 #if SVBRDF_TU_MAIN
 namespace {
 thread_local char g_err[256] = "";
+std::atomic<unsigned long long> g_launches{0};      // svbrdf_debug_launch_count()
 }
 int svbrdf_internal_fail(int code, const char *what)
 {
@@ -1469,6 +1612,7 @@ int svbrdf_internal_launch_status(const char *what)
         std::snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
         return (int)e;
     }
+    g_launches.fetch_add(1, std::memory_order_relaxed);      // every entry point enqueues exactly one kernel and ends here
     return 0;
 }
 #endif
@@ -1659,6 +1803,58 @@ int svbrdf_render_fwd_ragged(const float *maps, const float *scenes, const int *
     if (R < 0) return fail(SVBRDF_ERR_DIMS, "render_fwd_ragged: R must be >= 0");
     if (R == 0) return check_dims(B, 1, H, W);          // nothing to render
     return render_fwd_impl(maps, scenes, xrow, out, offsets, 0, 0, B, 1, H, W, stream);
+}
+
+// K1 + sensor-noise epilogue (render_inputs, dataset.py:206-219).  `sigma` null: clamp only.
+static int render_inputs_impl(const char *who, bool on_host, const float *maps, const float *scenes, const float *sigma,
+                              unsigned long long seed, unsigned long long offset, const float *xrow, float *out,
+                              int B, int S, int H, int W, void *stream)
+{
+    if (!maps || !scenes || !xrow || !out) return fail(SVBRDF_ERR_NULL, "render_inputs: null pointer");
+    if (int e = check_dims(B, S, H, W)) return e;
+    if (on_host && (long long)B * S > SVBRDF_HOST_SCENES_MAX_ROWS)
+        return fail(SVBRDF_ERR_DIMS, "render_inputs_host_scenes: the table exceeds SVBRDF_HOST_SCENES_MAX_ROWS (upload scenes "
+                                     "and noise levels and use svbrdf_render_inputs)");
+    if (!aligned(maps, 4) || !aligned(scenes, 4) || !aligned(sigma, 4) || !aligned(xrow, 4) || !aligned(out, 4))
+        return fail(SVBRDF_ERR_ALIGN, "render_inputs: pointers must be 4-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int vec = pick_vec(env_vec("SVBRDF_K1_VEC", 4), W, {maps, xrow, out});
+    const dim3 grid = grid_for(B, H, W, vec), block(kThreads);
+    const PhiloxKey key{(unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32)};
+#define SVBRDF_LAUNCH_PHOTOS(V, E)                                                                                     \
+    do {                                                                                                               \
+        if (on_host)                                                                                                   \
+            hipLaunchKernelGGL((k_render_inputs_inl<V, E>), grid, block, 0, st, block_arg, key, maps, xrow, out, S, H, W); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_render_inputs<V, E>), grid, block, 0, st, maps, scenes, sigma, key, xrow, out, S, H, W); \
+    } while (0)
+    PhotoBlock block_arg;          // only the first B*S rows / levels are ever read
+    if (on_host) {
+        std::memcpy(block_arg.v, scenes, (size_t)B * S * 9 * sizeof(float));
+        if (sigma) std::memcpy(block_arg.sigma, sigma, (size_t)B * S * sizeof(float));
+    }
+    if (sigma) {
+        if (vec == 4) SVBRDF_LAUNCH_PHOTOS(4, 2); else if (vec == 2) SVBRDF_LAUNCH_PHOTOS(2, 2); else SVBRDF_LAUNCH_PHOTOS(1, 2);
+    } else {
+        if (vec == 4) SVBRDF_LAUNCH_PHOTOS(4, 1); else if (vec == 2) SVBRDF_LAUNCH_PHOTOS(2, 1); else SVBRDF_LAUNCH_PHOTOS(1, 1);
+    }
+#undef SVBRDF_LAUNCH_PHOTOS
+    return launch_status(who);
+}
+
+int svbrdf_render_inputs(const float *maps, const float *scenes, const float *noise_std, unsigned long long seed,
+                         unsigned long long offset, const float *xrow, float *out, int B, int S, int H, int W, void *stream)
+{
+    return render_inputs_impl("render_inputs launch", false, maps, scenes, noise_std, seed, offset, xrow, out, B, S, H, W,
+                              stream);
+}
+
+int svbrdf_render_inputs_host_scenes(const float *maps, const float *scenes_host, const float *noise_std_host,
+                                     unsigned long long seed, unsigned long long offset, const float *xrow, float *out,
+                                     int B, int S, int H, int W, void *stream)
+{
+    return render_inputs_impl("render_inputs_host_scenes launch", true, maps, scenes_host, noise_std_host, seed, offset,
+                              xrow, out, B, S, H, W, stream);
 }
 
 static int render_bwd_impl(const float *maps, const float *scenes, const float *xrow, const float *grad_out,
@@ -1856,6 +2052,20 @@ int svbrdf_mix_materials(const float *svbrdf0, const float *svbrdf1, const float
     else hipLaunchKernelGGL(k_mix_materials<1>, grid, block, 0, st, svbrdf0, svbrdf1, alpha, out, plane);
     return launch_status("mix_materials launch");
 }
+
+int svbrdf_debug_copy(float *dst, const float *src, size_t n, void *stream)
+{
+    if (!dst || !src) return fail(SVBRDF_ERR_NULL, "debug_copy: null pointer");
+    if (n == 0 || (n & 3) != 0) return fail(SVBRDF_ERR_DIMS, "debug_copy: n must be a positive multiple of 4 floats");
+    if (!aligned(dst, 16) || !aligned(src, 16)) return fail(SVBRDF_ERR_ALIGN, "debug_copy: pointers must be 16-byte aligned");
+    const size_t n4 = n / 4, per_block = (size_t)kThreads * kCopyUnroll, blocks = (n4 + per_block - 1) / per_block;
+    if (blocks > 0x7fffffffULL) return fail(SVBRDF_ERR_DIMS, "debug_copy: n too large");
+    hipLaunchKernelGGL(k_copy_vec4, dim3((unsigned)blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<vec4f *>(dst), reinterpret_cast<const vec4f *>(src), n4);
+    return launch_status("debug_copy launch");
+}
+
+unsigned long long svbrdf_debug_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
 
 int svbrdf_debug_clock_probe(unsigned long long *out_dev, unsigned long long ticks_100mhz, void *stream)
 {

@@ -7,12 +7,18 @@ Keeps the reference's plugin interface (development/multiImage_pytorch/renderers
   * ``scene`` any object with ``.camera.pos``, ``.light.pos``, ``.light.color``
     (3-sequences, ndarrays or tensors -- dataset.py:210 passes tensors),
   * differentiable w.r.t. ``svbrdf``.
+  * a HOST ``svbrdf`` (the reference's dataloader renders missing input photos in the main process with CPU tensors,
+    dataset.py:94-98 -> :206-212) is staged through pinned memory to the current ROCm device, rendered by the same
+    kernel K1 and returned as a CPU tensor (forward only; see ``_HostStaging``).  Without a usable ROCm device the
+    call raises ``NativeLibraryError`` -- there is no CPU implementation.
 The arithmetic (renderers.py:8-104) runs in the hand-written HIP kernels K1 (forward) and
 K2 (analytic backward, forward recomputed in registers) of csrc/svbrdf_kernels.hip.
 
 Extension (not in the reference): ``render_many(scene_table, svbrdf)`` renders S scenes per
 map in one launch, reading the maps once.
 """
+import threading
+
 import torch
 
 from . import _hostext, _native, environment
@@ -96,6 +102,65 @@ def differentiable_render_backward(maps, scenes, grad_out):
     return grad.to(maps.dtype)
 
 
+class _HostStaging:
+    """The reference's SECOND caller of ``render`` hands it host tensors: ``SvbrdfDataset.render_inputs``
+    (dataset.py:206-212) runs in the main process (main.py:63: ``num_workers=0``), renders one ``[1,12,H,W]`` CPU map per
+    missing input photo and ``torch.cat``s the CPU result with the photos it read (dataset.py:98).  This class serves that
+    call shape on the GPU: maps -> pinned slot -> device (async copy) -> K1 with the scene row by value -> pinned slot
+    (async copy) -> a fresh pageable CPU tensor, all on the current stream of the current device, one event wait at the
+    end.  Slots are cached per (device, shape): a dataloader calls with one shape for its whole life.  Forward only."""
+
+    _lock = threading.Lock()
+    _slots = {}
+
+    @classmethod
+    def usable_device(cls):
+        """the device a host tensor is rendered on, or a NativeLibraryError saying why there is none"""
+        bad_fork = getattr(torch.cuda, "_is_in_bad_fork", None)
+        if bad_fork is not None and bad_fork():
+            raise _native.NativeLibraryError(
+                "LocalRenderer.render got a CPU tensor in a forked worker process whose parent had already initialised the "
+                "ROCm runtime: a forked child cannot use the GPU, and this engine has no CPU implementation.  Use "
+                "num_workers=0 (the reference's main.py:63), a 'spawn' DataLoader context, synthesis.render_inputs on the "
+                "device, or keep the reference's own renderer for the dataloader: svbrdf_estimation_amd.install("
+                "patch_renderer=False)")
+        if not torch.cuda.is_available():
+            raise _native.NativeLibraryError(
+                "LocalRenderer.render got a CPU tensor and no ROCm device is available: the MI355X engine only computes on "
+                "the GPU (no CPU fallback).  On a machine without a GPU keep the reference's own renderer: "
+                "svbrdf_estimation_amd.install(patch_renderer=False)")
+        return torch.device("cuda", torch.cuda.current_device())
+
+    @classmethod
+    def render(cls, maps, row):
+        """maps: host [B,12,H,W] (any strides); row: host [1,9] -> host [B,3,H,W]"""
+        dev = cls.usable_device()
+        if maps.dtype != torch.float32:
+            # double maps: the reference's mixed-precision path, not worth pinned slots of its own
+            with torch.no_grad():
+                return _native.render_fwd(maps.detach().to(dev), row).view(maps.shape[0], 3, *maps.shape[-2:]).cpu()
+        key = (dev.index, tuple(maps.shape))
+        with cls._lock:
+            slot = cls._slots.get(key)
+            if slot is None:
+                B, _, H, W = maps.shape
+                slot = (torch.empty(maps.shape, dtype=torch.float32, pin_memory=True),
+                        torch.empty(maps.shape, dtype=torch.float32, device=dev),
+                        torch.empty((B, 3, H, W), dtype=torch.float32, pin_memory=True), torch.cuda.Event())
+                if len(cls._slots) >= 8:            # a new shape after eight: drop the oldest set of buffers
+                    cls._slots.pop(next(iter(cls._slots)))
+                cls._slots[key] = slot
+            pin_in, dev_in, pin_out, done = slot
+            with torch.no_grad():
+                pin_in.copy_(maps)                                  # host copy (gathers a strided / expanded view)
+                dev_in.copy_(pin_in, non_blocking=True)             # H2D from pinned memory: asynchronous
+                out = _native.render_fwd(dev_in, row)               # K1, scene row by value: [B,1,3,H,W]
+                pin_out.copy_(out.view(pin_out.shape), non_blocking=True)
+                done.record(torch.cuda.current_stream(dev))
+                done.synchronize()
+                return pin_out.clone()                              # pageable, the caller's to keep (dataset.py:98 cats it)
+
+
 class LocalRenderer:
     """Drop-in for renderers.LocalRenderer (no constructor arguments)."""
 
@@ -114,6 +179,12 @@ class LocalRenderer:
         # the scene's nine floats stay on the host and travel with the launch: one dispatch per call, no H2D copy
         # (the reference uploads camera, light and colour with three synchronous copies, renderers.py:79,91,98)
         row = environment.scene_to_row(scene).view(1, 9)           # one scene, shared by every map of the batch
+        if not maps.is_cuda:
+            if maps.requires_grad and torch.is_grad_enabled():
+                raise _native.NativeLibraryError(
+                    "LocalRenderer.render got a CPU tensor that requires grad: host tensors are rendered forward-only (the "
+                    "dataloader's call, dataset.py:206-212); move the maps to the ROCm device to differentiate through render")
+            return _HostStaging.render(maps, row)
         ext = _hostext.module() if maps.is_cuda else None
         if ext is not None and maps.dtype == torch.float32 and maps.device.index == torch.cuda.current_device():
             # native host path (csrc/host_ext.cpp): same two kernels through the same C ABI, C++ autograd node

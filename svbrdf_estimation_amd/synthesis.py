@@ -9,9 +9,11 @@ and all ``count`` photos of all batch items are rendered by ONE launch of the fo
 K1, reading each SVBRDF once.
 
 Noise: the reference draws the per-pixel noise from the CPU generator.  ``noise="cpu"`` does the
-same (bit-identical noise field, costs a 3*H*W draw + upload per image); ``noise="device"``
-(default) draws it with the device generator (fast, statistically identical, different
-numbers); ``noise=None`` disables it.
+same (bit-identical noise field, costs a 3*H*W draw + upload per image).  ``noise="device"``
+(default) fuses noise and clamp into K1's store (``svbrdf_render_inputs``): the levels are drawn on
+the host, the field is counter-based (Philox4x32-10 keyed by torch's device generator), the whole
+call is ONE kernel launch that writes every photo once -- statistically identical, different
+numbers.  ``noise=None``: the same launch without the field (clamp only).
 """
 import math
 
@@ -53,9 +55,15 @@ def noise_std():
     return torch.exp(torch.empty(1).normal_(mean=np.log(0.005), std=0.3)).numpy()[0]
 
 
-def render_inputs(svbrdf, count, use_augmentation=True, noise="device"):
+def noise_levels(n):
+    """the levels of n photos in ONE host draw, same distribution as n calls of noise_std() (dataset.py:215)"""
+    return torch.exp(torch.empty(n).normal_(mean=math.log(0.005), std=0.3))
+
+
+def render_inputs(svbrdf, count, use_augmentation=True, noise="device", generator=None):
     """svbrdf [12,H,W] (one sample, like the reference) or [B,12,H,W] on a ROCm device ->
-    [count,3,H,W] / [B,count,3,H,W] linear-RGB input photos in [0,1]."""
+    [count,3,H,W] / [B,count,3,H,W] linear-RGB input photos in [0,1].  `generator`: the torch device generator the
+    ``noise="device"`` field is keyed by (default: the device's default generator, i.e. ``torch.cuda.manual_seed``)."""
     single = svbrdf.dim() == 3
     maps = svbrdf.unsqueeze(0) if single else svbrdf
     if maps.dim() != 4 or maps.shape[1] != 12:
@@ -72,14 +80,17 @@ def render_inputs(svbrdf, count, use_augmentation=True, noise="device"):
                 std = noise_std()
                 per_image.append(torch.zeros(1, 3, H, W).normal_(mean=0.0, std=std))
             fields.append(torch.cat(per_image, dim=0))
-    # K1: [B,count,3,H,W]; the host table travels with the launch when it fits the argument block (pinned ring otherwise)
-    out = _native.render_fwd(maps.detach(), torch.stack(tables, dim=0))
+    table = torch.stack(tables, dim=0)
     if noise == "cpu":
+        # K1: [B,count,3,H,W]; the host table travels with the launch when it fits the argument block (pinned ring otherwise)
+        out = _native.render_fwd(maps.detach(), table)
         out = out + torch.stack(fields, dim=0).to(maps.device, non_blocking=True)
-    elif noise == "device":
-        stds = torch.tensor([[float(noise_std()) for _i in range(count)] for _b in range(B)], device=maps.device)
-        out = out + torch.randn_like(out) * stds.view(B, count, 1, 1, 1)
-    out = out.clamp_(0.0, 1.0)
+        out = out.clamp_(0.0, 1.0)
+    else:
+        # ONE launch: render + sigma * N(0,1) + clamp in K1's epilogue; levels of all B*count photos in one host draw
+        levels = noise_levels(B * count).view(B, count) if noise == "device" else None
+        seed, offset = _native.device_philox_state(maps.device, generator) if noise == "device" else (0, 0)
+        out = _native.render_inputs(maps.detach(), table, levels, seed, offset)
     return out[0] if single else out
 
 

@@ -53,3 +53,26 @@ int perf_loop_mix(mix_fn_t fn, int n, int first, int sets, const float *const *a
     }
     return 0;
 }
+
+typedef int (*copy_fn_t)(float *, const float *, size_t, void *);
+typedef int (*render_inputs_fn_t)(const float *, const float *, const float *, unsigned long long, unsigned long long,
+                                  const float *, float *, int, int, int, int, void *);
+
+/* svbrdf_debug_copy: the copy bandwidth of the box */
+int perf_loop_copy(copy_fn_t fn, int n, float *dst, const float *src, size_t n_floats, void *stream)
+{
+    int k, rc;
+    for (k = 0; k < n; ++k)
+        if ((rc = fn(dst, src, n_floats, stream)) != 0) return rc;
+    return 0;
+}
+
+/* svbrdf_render_inputs (device tables): K1 + sensor noise + clamp; the offset advances like a device generator's */
+int perf_loop_render_inputs(render_inputs_fn_t fn, int n, int first, const float *maps, const float *scenes, const float *noise_std,
+                            unsigned long long seed, const float *xrow, float *out, int B, int S, int H, int W, void *stream)
+{
+    int k, rc;
+    for (k = first; k < first + n; ++k)
+        if ((rc = fn(maps, scenes, noise_std, seed, 4ull * (unsigned long long)k, xrow, out, B, S, H, W, stream)) != 0) return rc;
+    return 0;
+}

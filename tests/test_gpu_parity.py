@@ -786,6 +786,144 @@ def test_render_inputs_matches_reference_dataloader(dev, oracle, golden):
     assert abs(resid.mean().item()) < 2e-3 and 1e-3 < resid.std().item() < 3e-2
 
 
+def test_render_inputs_fused_noise_and_clamp_epilogue(dev):
+    """SURVEY section 8 row f3 "K1 (+ Gaussian noise, clamp [0,1])" (dataset.py:215-217) as ONE launch,
+    svbrdf_render_inputs*: without levels it is bitwise clamp(K1); with levels the photo is
+    clamp(K1 + sigma_image * n) where n is the counter-based field the header defines -- checked element by element against
+    the numpy restatement of Philox4x32-10 + Box-Muller (tests/philox_ref.py, pinned by the published vectors in the CPU
+    suite) for every vector width, for host and device tables, and statistically per image."""
+    import philox_ref
+    from svbrdf_estimation_amd import _native, synthesis
+    seed, offset = 0x1234ABCD5678, 0x100000040
+    for H, B, S in ((32, 3, 2), (30, 2, 3), (31, 2, 2), (64, 2, 5)):            # W % 4 == 0 / % 2 == 0 / odd: VEC 4, 2, 1
+        maps = _t(synth.make_maps(900 + H, B, H), dev)
+        torch.manual_seed(H)
+        table = torch.stack([synthesis.input_scene_table(S, True) for _ in range(B)])
+        levels = (synthesis.noise_levels(B * S) * 4.0).view(B, S)               # 0.01 .. 0.05: well above fp32 resolution
+        plain = _native.render_fwd(maps, table)
+        # no levels: clamp only, bit for bit, host table and device table
+        assert torch.equal(_native.render_inputs(maps, table), plain.clamp(0.0, 1.0))
+        assert torch.equal(_native.render_inputs(maps, table.to(dev)), plain.clamp(0.0, 1.0))
+        noisy = _native.render_inputs(maps, table, levels, seed, offset)
+        assert torch.equal(noisy, _native.render_inputs(maps, table.to(dev), levels.to(dev), seed, offset))
+        assert torch.equal(noisy, _native.render_inputs(maps, table, levels, seed, offset))      # a pure function of its inputs
+        assert not torch.equal(noisy, _native.render_inputs(maps, table, levels, seed, offset + 4))
+        assert not torch.equal(noisy, _native.render_inputs(maps, table, levels, seed + 1, offset))
+        field = philox_ref.normal_field(seed, offset, plain.numel()).reshape(plain.shape)
+        want = np.clip(_np(plain).astype(np.float64) + levels.numpy().astype(np.float64)[:, :, None, None, None] * field, 0.0, 1.0)
+        err = np.abs(_np(noisy) - want)
+        # v_log / v_sqrt / v_sin / v_cos are ~1 ulp of their results; the field enters scaled by sigma <= 0.05
+        assert err.max() <= 2e-7 + 3e-6 * float(levels.max()), (H, err.max())
+        assert noisy.min().item() >= 0.0 and noisy.max().item() <= 1.0
+        # statistics per image, on pixels no clamp touched: residual / sigma ~ N(0,1)
+        for b in range(B):
+            for s_ in range(S):
+                clean = _np(plain[b, s_])
+                inner = (clean > 0.3) & (clean < 0.7)
+                if inner.sum() < 200:
+                    continue
+                z = (_np(noisy[b, s_])[inner] - clean[inner]) / float(levels[b, s_])
+                n = z.size
+                assert abs(z.mean()) < 4.0 / np.sqrt(n) and abs(z.var() - 1.0) < 4.0 * np.sqrt(2.0 / n), (H, b, s_, z.mean(), z.var())
+    # NaN maps stay NaN through the clamp (torch.clamp's behaviour), like clamp(K1)
+    bad = _t(synth.make_maps(950, 1, 16), dev)
+    bad[0, 4, 3, 5] = float("nan")
+    tab = torch.stack([synthesis.input_scene_table(1, False)])
+    a, b = _native.render_inputs(bad, tab), _native.render_fwd(bad, tab).clamp(0.0, 1.0)
+    assert torch.isnan(a).sum().item() == torch.isnan(b).sum().item() > 0 and torch.equal(torch.nan_to_num(a, 7.0), torch.nan_to_num(b, 7.0))
+    # through synthesis.render_inputs: ONE kernel launch per call; keyed by torch's device generator
+    maps = _t(synth.make_maps(960, 4, 32), dev)
+    for noise in ("device", None):
+        before = _native.launch_count()
+        synthesis.render_inputs(maps, 3, noise=noise)
+        assert _native.launch_count() - before == 1, noise
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        torch.cuda.manual_seed(77)
+        outs.append((synthesis.render_inputs(maps, 2), synthesis.render_inputs(maps, 2)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    torch.manual_seed(3)
+    torch.cuda.manual_seed(77)
+    first = synthesis.render_inputs(maps, 2)
+    torch.manual_seed(3)                                 # same scenes and levels, the device generator has moved on
+    assert not torch.equal(first, synthesis.render_inputs(maps, 2))
+    # more photos than the argument block holds: tables are uploaded, same field
+    big = _t(synth.make_maps(961, 40, 16), dev)
+    torch.manual_seed(9)
+    table = torch.stack([synthesis.input_scene_table(8, True) for _ in range(40)])       # 320 rows > 288
+    levels = synthesis.noise_levels(320).view(40, 8)
+    assert 40 * 8 > _native.host_scenes_max_rows()
+    via_upload = _native.render_inputs(big, table, levels, 5, 8)
+    assert torch.equal(via_upload, _native.render_inputs(big, table.to(dev), levels.to(dev), 5, 8))
+    lib = _native._load()
+    out = torch.empty_like(via_upload)
+    rc = lib.svbrdf_render_inputs_host_scenes(big.data_ptr(), table.data_ptr(), levels.data_ptr(), 5, 8,
+                                               _native.xrow(dev, 16).data_ptr(), out.data_ptr(), 40, 8, 16, 16, None)
+    assert rc == -2 and b"SVBRDF_HOST_SCENES_MAX_ROWS" in lib.svbrdf_last_error()
+
+
+def test_render_of_a_host_tensor_is_the_device_call_and_serves_the_reference_dataloader(dev, golden):
+    """the reference's SECOND caller of ``render`` is its dataloader, in the main process, with CPU
+    tensors -- ``renderer.render(scene, svbrdf.unsqueeze(0))`` with tensor-valued positions and colour, CPU noise added to
+    the CPU result, ``torch.cat`` of CPU photos (dataset.py:94-98, :206-221).  The call is served by K1 through a pinned
+    round trip: the result is a CPU tensor, bit for bit the device call's, and the reference's loop, restated here call by
+    call around it, reproduces the photos AND the generator state of the reference's own run (g10)."""
+    from svbrdf_estimation_amd import NativeLibraryError, environment as env, renderers, synthesis
+    from tolerances import MAX_WIDENED_RENDER, _record
+    g = golden("g10_render_inputs.npz")
+    renderer = renderers.LocalRenderer()
+    for aug in (0, 1):
+        for count in (1, 4):
+            k = "aug%d_n%d" % (aug, count)
+            svbrdf = torch.from_numpy(g[k + "__maps"])                       # [12,32,32] on the HOST, like dataset.py:85
+            torch.manual_seed(int(g[k + "__seed"]))
+            table = synthesis.input_scene_table(count, bool(aug))            # dataset.py:172-204, the reference's draws
+            view_poses, light_poses, light_colors = table[:, 0:3], table[:, 3:6], table[:, 6:9]
+            renderings = []
+            for i in range(count):                                           # dataset.py:206-219, call for call
+                scene = env.Scene(env.Camera(view_poses[i]), env.Light(light_poses[i], light_colors[i]))
+                rendering = renderer.render(scene, svbrdf.unsqueeze(0))
+                assert rendering.device.type == "cpu" and tuple(rendering.shape) == (1, 3, 32, 32)
+                assert not rendering.is_pinned() and not rendering.requires_grad
+                on_device = renderer.render(scene, svbrdf.unsqueeze(0).to(dev))
+                assert torch.equal(rendering, on_device.cpu()), (k, i)
+                std = torch.exp(torch.Tensor(1).normal_(mean=np.log(0.005), std=0.3)).numpy()[0]
+                noise = torch.zeros_like(rendering).normal_(mean=0.0, std=std)
+                renderings.append(torch.clamp(rendering + noise, min=0.0, max=1.0))
+            out = torch.cat(renderings, dim=0)
+            assert np.array_equal(torch.get_rng_state().numpy()[:64], g[k + "__rng_after"]), k
+            ref = g[k + "__out"]
+            err = np.abs(out.numpy() - ref)
+            outside = int((err > 1e-5 * np.abs(ref) + 2e-6).sum())           # same bound as the device synthesis above
+            _record("host-tensor render, dataloader loop " + k, "outside 1e-5 rel + 2e-6", outside, err.size,
+                    min(MAX_WIDENED_RENDER, 8 * count))
+            assert outside <= min(MAX_WIDENED_RENDER, 8 * count), (k, outside, err.max())
+            assert err.max() <= 3e-5, (k, err.max())
+    # shapes and views the staging must gather: 3-D input, a batch with the one scene, a strided view, a second call
+    # reusing the slot with other data, 256x256
+    scene = env.Scene(env.Camera([0.1, -0.2, 2.0]), env.Light(np.array([0.4, 0.3, 1.5]), torch.tensor([30.0, 28.0, 31.0])))
+    for shape in ((12, 16, 16), (3, 12, 16, 16), (1, 12, 256, 256)):
+        for seed in (1, 2):
+            host = torch.from_numpy(synth.make_maps(700 + seed, shape[0] if len(shape) == 4 else 1, shape[-1]))
+            host = host[0] if len(shape) == 3 else host
+            got = renderer.render(scene, host)
+            assert got.device.type == "cpu" and torch.equal(got, renderer.render(scene, host.to(dev)).cpu())
+    wide = torch.from_numpy(synth.make_maps(703, 2, 24))
+    strided = wide.transpose(-1, -2)                                         # a non-contiguous view: gathered by the host copy
+    assert not strided.is_contiguous()
+    assert torch.equal(renderer.render(scene, strided), renderer.render(scene, strided.to(dev)).cpu())
+    dbl = wide.double()
+    got = renderer.render(scene, dbl)
+    assert got.dtype == torch.float64 and got.device.type == "cpu"
+    assert torch.equal(got, renderer.render(scene, dbl.to(dev)).cpu())
+    # forward only: a host tensor that wants a gradient is refused, never computed somewhere else
+    with pytest.raises(NativeLibraryError):
+        renderer.render(scene, wide.clone().requires_grad_(True))
+    with torch.no_grad():                                                    # ... unless nobody records a graph
+        assert torch.equal(renderer.render(scene, wide.clone().requires_grad_(True)), renderer.render(scene, wide))
+
+
 # ---------------------------------------------------------------- native host path vs ctypes path
 
 def test_host_extension_and_ctypes_paths_are_bitwise_identical(dev, golden):

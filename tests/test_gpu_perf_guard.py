@@ -20,23 +20,27 @@ How one figure is measured (``measure``):
   * best of three repeats (a guard asks "can the kernel still do it", not "what does it do on average").
 
 Thresholds and where they come from (cycles = time per launch x clock under that load; measured by this harness on
-two boxes of round 5, profiles/r05_perf_guard.json, clock 2.38-2.40 GHz under every K3 variant):
-  K3 config 2 (B = 8, 256x256, 9 scenes, tied roughness)   <= 93,000 cycles per launch      measured 85.5-87.1 k
-  K3 config 2, MixedLoss (the training loss)               <= 98,500                        measured 91.2-91.4 k
-  K3 config 2, untied roughness (three lobes)              <= 129,000                       measured 119.2-119.4 k
-  K3 config-5 shape (B = 8, 512x512, 11 + 21 scenes)       <= 967,000                       measured 893.9-895.9 k
-        = today + 7-8 %.  Round 3's kernel took 10 % longer than round 4's on one box (profiles/r04_k3_ab.txt: 39.7 vs
-        35.9 us), i.e. ~96 k of these cycles at config 2: the bound sits between the two.
-        NOTE on the 86 k the round-4 review proposed for config 2: that figure (and the 78-80 k "cycles per launch" of
-        BENCH_r04.json / profiles/r04_bench.json) paired the timed region's duration with a clock read in a LATER
-        interval by a probe of its own.  The clock under this kernel is not one number: it moves between 2.0 and 2.4 GHz
-        within milliseconds, differs by box, and sags to ~1.75 GHz for ~5 ms when load follows an idle period
-        (tools/clock_timeline.py, profiles/r05_clock_timeline*.txt) -- so that pairing is good to +-8 %, and it read low.
-        Here the probe opens with the timed launches (same event) and spans ~90 % of them; by this harness today's build
-        gives 85.5-88 k on boxes at 2.39 and at ~2.2 GHz.  bench.py pairs clock and duration of one interval since round 5.
+five boxes of rounds 5 and 6, profiles/r05_perf_guard.json, profiles/r06_perf_guard.json; they agree within 1.5 %):
+  K3 config 2 (B = 8, 256x256, 9 scenes, tied roughness)   <= 90,000 cycles per launch      measured 85.5-87.6 k
+  K3 config 2, MixedLoss (the training loss)               <= 95,000                        measured 91.2-92.1 k
+  K3 config 2, untied roughness (three lobes)              <= 124,000                       measured 119.2-122.1 k
+  K3 config-5 shape (B = 8, 512x512, 11 + 21 scenes)       <= 930,000                       measured 893.9-895.9 k
+        = today + 2-4 % (round 5 shipped + 7-8 %; the round-5 review asked for what five agreeing boxes support).  The
+        repeat that is kept is the one with the FEWEST CYCLES (clock and duration of the same repeat), every repeat is
+        recorded in perf_guard.json.
+        NOTE on cycles: the clock under this kernel is not one number -- it moves between 2.0 and 2.4 GHz within
+        milliseconds, differs by box, and sags to ~1.75 GHz for ~5 ms when load follows an idle period
+        (tools/clock_timeline.py, profiles/r05_clock_timeline*.txt).  Here the probe opens with the timed launches (same
+        event) and spans ~90 % of them; bench.py pairs clock and duration of one interval since round 5.
   K1 / K2 (288 renders of 256x256, one per map) and K4 (64 samples) >= 0.72 of 8 TB/s
-        BENCH_r04.json: 0.845 / 0.791 / 0.760; this harness: 0.840 / 0.808 / 0.779.  HBM-bound: judged in bytes per
+        BENCH_r05.json: 0.841 / 0.792 / 0.780; this harness: 0.834 / 0.810 / 0.773.  HBM-bound: judged in bytes per
         second (the HBM clock is not the shader clock).
+  svbrdf_debug_copy (1 GiB -> 1 GiB, beyond the Infinity Cache)       >= 0.72 of 8 TB/s
+        the copy bandwidth of the box (MI355X_MICROARCH.md: 6.29 TB/s = 0.79): what "HBM-bound" can reach here, and the
+        denominator of bench.py's frac_of_measured_copy_peak.
+  K1 + sensor noise + clamp (svbrdf_render_inputs, 288 photos of 256x256, one per map): recorded, and guarded against
+        the three-pass form it replaces (K1, then torch's randn / multiply-add / clamp passes): >= 1.5x faster.
+  one kernel launch per training step of the loss (svbrdf_debug_launch_count around 64 steps on a NON-LEAF input).
 
 Run as a script (``python tests/test_gpu_perf_guard.py``) it prints the measurements as JSON and writes
 gpurun_out/perf_guard.json -- how the thresholds were obtained.
@@ -59,11 +63,13 @@ pytestmark = pytest.mark.gpu
 HBM_PEAK = 8.0e12
 
 # ---- thresholds (see the module docstring) ------------------------------------------------------------------------
-K3_CONFIG2_MAX_CYCLES = 93_000
-K3_MIXED_MAX_CYCLES = 98_500
-K3_UNTIED_MAX_CYCLES = 129_000
-K3_CONFIG5_MAX_CYCLES = 967_000
+K3_CONFIG2_MAX_CYCLES = 90_000
+K3_MIXED_MAX_CYCLES = 95_000
+K3_UNTIED_MAX_CYCLES = 124_000
+K3_CONFIG5_MAX_CYCLES = 930_000
 HBM_KERNELS_MIN_FRAC = 0.72
+COPY_MIN_FRAC = 0.72
+FUSED_PHOTOS_MIN_SPEEDUP = 1.5
 
 _fp = ctypes.c_void_p
 
@@ -94,7 +100,8 @@ class Harness:
         self.native = _native
         self.lib = _native._load()
         self.loops = _build_launch_loops()
-        for name in ("perf_loop_loss", "perf_loop_render_fwd", "perf_loop_render_bwd", "perf_loop_mix"):
+        for name in ("perf_loop_loss", "perf_loop_render_fwd", "perf_loop_render_bwd", "perf_loop_mix", "perf_loop_copy",
+                     "perf_loop_render_inputs"):
             getattr(self.loops, name).restype = ctypes.c_int
         self.dev = dev
         self.sa, self.sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
@@ -111,7 +118,9 @@ class Harness:
 
     def measure(self, enqueue, est_us, want_clock=True, repeats=3):
         """enqueue(first, n): enqueues launches first .. first+n-1 on stream ``self.sa`` (from C: tests/c_host/launch_loop.c).
-        -> dict(us_per_launch, clock_GHz, cycles_per_launch), best repeat."""
+        -> dict(us_per_launch, clock_GHz, cycles_per_launch, repeats=[every valid repeat]): the best repeat -- by CYCLES when
+        the clock is read (the assertion is on cycles, and the chip lowers its clock for denser issue: the fastest repeat is
+        not always the one with the fewest cycles), by microseconds otherwise."""
         dev, sa, sb = self.dev, self.sa, self.sb
         n = 4 * int(max(3, min(30, 1000.0 / est_us)))       # ~4 ms of launches, in four chunks
         q = n // 4
@@ -121,7 +130,7 @@ class Harness:
         while time.perf_counter() - t0 < 0.3:
             enqueue(0, 32)
             torch.cuda.synchronize(dev)
-        best, invalid, valid = None, [], 0
+        best, invalid, valid, every = None, [], 0, []
         for _ in range(repeats + 2):            # up to two attempts may be spoilt by the host
             e0 = torch.cuda.Event(enable_timing=True)
             marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -155,12 +164,16 @@ class Harness:
                 ghz = cyc / ticks * 0.1
             res = {"us_per_launch": us, "launches": n, "clock_GHz": ghz,
                    "cycles_per_launch": us * ghz * 1e3 if ghz else None, "host_enqueue_ms": host_ms}
-            if best is None or us < best["us_per_launch"]:
+            every.append(dict(res))
+            key = "cycles_per_launch" if want_clock else "us_per_launch"
+            if best is None or res[key] < best[key]:
                 best = res
             valid += 1
             if valid >= repeats:
                 break
         assert best is not None, "no valid measurement in %d attempts: %s" % (repeats + 2, invalid)
+        best = dict(best)
+        best["repeats"] = every
         return best
 
     # ---- the cases ------------------------------------------------------------------------------------------
@@ -240,6 +253,42 @@ class Harness:
         return enqueue, [alpha, a, b, outs, p_a, p_b, p_o], 144.0 * H * H * B
 
 
+    def copy_calls(self, gib=1.0):
+        dev = self.dev
+        n = int(gib * 2 ** 30) // 4                      # floats; src + dst = 2 GiB: far beyond the 256 MiB Infinity Cache
+        src = torch.empty(n, device=dev).uniform_(-1.0, 1.0)
+        dst = torch.empty_like(src)
+        fn, st = self._fn("svbrdf_debug_copy"), _fp(self.sa.cuda_stream)
+
+        def enqueue(first, k):
+            rc = self.loops.perf_loop_copy(fn, ctypes.c_int(k), _fp(dst.data_ptr()), _fp(src.data_ptr()), ctypes.c_size_t(n), st)
+            assert rc == 0, self.lib.svbrdf_last_error()
+        torch.cuda.synchronize(dev)
+        return enqueue, [src, dst], 8.0 * n
+
+    def photo_calls(self):
+        """svbrdf_render_inputs, device tables: 288 maps, one photo each (the HBM-heaviest shape: 60 B per pixel)"""
+        from svbrdf_estimation_amd import synthesis
+        dev = self.dev
+        B, H = 288, 256
+        gen = torch.Generator().manual_seed(7)
+        maps = _maps(gen, B, H).to(dev)
+        torch.manual_seed(7)
+        table = torch.stack([synthesis.input_scene_table(1, True) for _ in range(B)]).to(dev)
+        levels = synthesis.noise_levels(B).to(dev)
+        xr = self.native.xrow(dev, H)
+        out = torch.empty(B, 1, 3, H, H, device=dev)
+        fn, st, c_i = self._fn("svbrdf_render_inputs"), _fp(self.sa.cuda_stream), ctypes.c_int
+
+        def enqueue(first, n):
+            rc = self.loops.perf_loop_render_inputs(fn, c_i(n), c_i(first), _fp(maps.data_ptr()), _fp(table.data_ptr()),
+                                                    _fp(levels.data_ptr()), ctypes.c_ulonglong(99), _fp(xr.data_ptr()),
+                                                    _fp(out.data_ptr()), c_i(B), c_i(1), c_i(H), c_i(H), st)
+            assert rc == 0, self.lib.svbrdf_last_error()
+        torch.cuda.synchronize(dev)
+        return enqueue, [maps, table, levels, xr, out], 60.0 * H * H * B
+
+
 @pytest.fixture(scope="module")
 def harness():
     assert torch.cuda.is_available(), "GPU tests need an MI355X (select CPU tests with -m 'not gpu')"
@@ -303,6 +352,90 @@ def test_mix_materials_hbm_fraction(harness):
     assert res["frac_of_hbm_peak"] >= HBM_KERNELS_MIN_FRAC, res
 
 
+def test_copy_kernel_reaches_the_copy_peak(harness):
+    """svbrdf_debug_copy on 1 GiB -> 1 GiB: the measured-copy peak of this box"""
+    calls, keep, nbytes = harness.copy_calls()
+    res = _record("copy_1GiB", harness.measure(calls, est_us=340.0, want_clock=False), nbytes)
+    assert res["frac_of_hbm_peak"] >= COPY_MIN_FRAC, res
+    src, dst = keep
+    assert torch.equal(src, dst)
+
+
+def test_fused_photo_synthesis_beats_the_three_pass_form(harness):
+    """K1 + noise + clamp in one launch (svbrdf_render_inputs) against what it replaces: K1, then torch's randn_like,
+    multiply-add and clamp passes over the photos (round 5's synthesis.render_inputs)."""
+    calls, keep, nbytes = harness.photo_calls()
+    res = _record("k1_noise_clamp_288_photos", harness.measure(calls, est_us=200.0, want_clock=False), nbytes)
+    maps, table, levels, xr, out = keep
+    dev = harness.dev
+    sig = levels.view(-1, 1, 1, 1, 1)
+
+    def three_pass():
+        o = harness.native.render_fwd(maps, table)
+        o = o + torch.randn_like(o) * sig
+        return o.clamp_(0.0, 1.0)
+    for _ in range(3):
+        three_pass()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        three_pass()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    old_us = 1e3 * e0.elapsed_time(e1) / 10
+    _RESULTS["k1_noise_clamp_288_photos"]["three_pass_form_us"] = old_us
+    _RESULTS["k1_noise_clamp_288_photos"]["speedup_over_three_pass_form"] = old_us / res["us_per_launch"]
+    print("[perf-guard] photos: fused %.1f us, K1 + randn + fma + clamp passes %.1f us" % (res["us_per_launch"], old_us))
+    assert old_us >= FUSED_PHOTOS_MIN_SPEEDUP * res["us_per_launch"], (old_us, res)
+
+
+def test_one_kernel_launch_per_training_step():
+    """values were tested bit-identical for the one-launch engine path, the launch COUNT was
+    asserted nowhere.  64 steps of ``loss.backward()`` on a NON-LEAF input (a network output: PyTorch's autograd engine
+    runs the node) enqueue exactly 64 kernels of this library -- no scale launch -- and, seen by torch's profiler, the
+    device ran exactly one kernel per step that is not the stand-in network's own: no ones-fill by the engine."""
+    from svbrdf_estimation_amd import _native, losses, renderers
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(3)
+    B, H, steps = 8, 256, 64
+    x = _maps(gen, B, H).to(dev).requires_grad_(True)
+    tgt = _maps(gen, B, H).to(dev)
+    for name, fn in (("RenderingLoss", losses.RenderingLoss(renderers.LocalRenderer())),
+                     ("MixedLoss", losses.MixedLoss(renderers.LocalRenderer()))):
+        def step():
+            x.grad = None
+            y = x * 1.0                    # a non-leaf: what a network output is to the loss
+            fn(y, tgt).backward()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        before = _native.launch_count()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        assert _native.launch_count() - before == steps, (name, _native.launch_count() - before)
+        assert x.grad is not None and torch.isfinite(x.grad).all()
+        # the whole device timeline of 16 steps: per step the stand-in's multiply, its backward (multiply) and ONE loss kernel
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            for _ in range(16):
+                step()
+            torch.cuda.synchronize(dev)
+        dev_type = getattr(torch.autograd, "DeviceType", None)
+        kernels = [e for e in prof.events() if dev_type is not None and e.device_type == dev_type.CUDA]
+        names = [e.name for e in kernels]
+        if names:           # kineto saw the device (it does on ROCm builds with roctracer; an empty trace proves nothing)
+            ours = [n for n in names if "k_rendering_loss" in n]
+            fills = [n for n in names if "fill" in n.lower() or "k_scale_inplace" in n]
+            _RESULTS["launches_per_step_" + name] = {"device_kernels_in_16_steps": len(names), "loss_kernels": len(ours),
+                                                     "fill_or_scale_kernels": len(fills), "distinct": sorted(set(names))[:12]}
+            assert len(ours) == 16 and not fills, (name, sorted(set(names)))
+        else:
+            _RESULTS["launches_per_step_" + name] = {"device_kernels_in_16_steps": None,
+                                                     "note": "torch.profiler reported no device events on this build"}
+
+
 if __name__ == "__main__":
     h = Harness(torch.device("cuda:0"))
     for name, (mk, est, clk) in {
@@ -312,7 +445,9 @@ if __name__ == "__main__":
             "k3_config5_shape": (lambda: h.k3_calls(8, 512, 11, 21, sets=2), 400.0, True),
             "k1_288_renders": (lambda: h.k12_calls("k1"), 170.0, False),
             "k2_288_renders": (lambda: h.k12_calls("k2"), 325.0, False),
-            "k4_64_samples": (lambda: h.k4_calls(), 100.0, False)}.items():
+            "k4_64_samples": (lambda: h.k4_calls(), 100.0, False),
+            "copy_1GiB": (lambda: h.copy_calls(), 340.0, False),
+            "k1_noise_clamp_288_photos": (lambda: h.photo_calls(), 200.0, False)}.items():
         if os.environ.get("PERF_GUARD_CASES") and name not in os.environ["PERF_GUARD_CASES"].split(","):
             continue
         calls, keep, nbytes = mk()

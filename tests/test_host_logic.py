@@ -66,12 +66,20 @@ def test_argument_errors_without_gpu():
     assert lib.svbrdf_rendering_loss_workspace_bytes(0, 9, 256, 256) == 0
 
 
-def test_no_cpu_fallback():
-    """the product path must fail loudly on CPU tensors instead of computing somewhere else"""
+def test_no_cpu_fallback(monkeypatch):
+    """no GPU => the product path fails loudly instead of computing somewhere else.  (With a ROCm device present a HOST tensor
+    handed to ``render`` -- the reference dataloader's call shape, dataset.py:206-212 -- is staged to the device and rendered
+    by K1, forward only: tests/test_gpu_parity.py.  Without a GPU every call must raise, and the message of
+    the renderer's must name the way out.)"""
     from svbrdf_estimation_amd import NativeLibraryError, environment, losses, renderers
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)      # the machine this test describes (true here anyway)
     sc = environment.Scene(environment.Camera([0, 0, 2.0]), environment.Light([0, 0, 2.0], [1.0, 1.0, 1.0]))
-    with pytest.raises(NativeLibraryError):
+    with pytest.raises(NativeLibraryError, match="patch_renderer=False"):
         renderers.LocalRenderer().render(sc, torch.zeros(12, 8, 8))
+    with pytest.raises(NativeLibraryError, match="patch_renderer=False"):
+        renderers.LocalRenderer().render(sc, torch.zeros(2, 12, 8, 8, dtype=torch.float64))
+    with pytest.raises(NativeLibraryError, match="forward-only"):       # refused before any device is looked for
+        renderers.LocalRenderer().render(sc, torch.zeros(12, 8, 8, requires_grad=True))
     with pytest.raises(NativeLibraryError):
         losses.RenderingLoss(renderers.LocalRenderer())(torch.zeros(1, 12, 8, 8), torch.zeros(1, 12, 8, 8))
     with pytest.raises(ValueError):
@@ -163,6 +171,31 @@ def test_input_synthesis_scene_tables_bit_exact(golden):
         synthesis.render_inputs(torch.zeros(9, 4, 4), 1)
     with pytest.raises(Exception):
         synthesis.render_inputs(torch.zeros(12, 4, 4), 1)      # CPU tensor: no fallback
+
+
+def test_noise_field_reference_generator_matches_the_published_philox_vectors():
+    """tests/philox_ref.py is the checker of the fused sensor-noise epilogue (svbrdf_render_inputs, GPU suite); its
+    Philox4x32-10 is pinned by the known-answer vectors the Random123 distribution ships for philox4x32 with 10 rounds
+    (counter, key -> output: zeros, all ones, digits of pi)."""
+    import philox_ref
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = tuple(int(v) for v in philox_ref.philox4x32_10(*ctr, *key))
+        assert got == want, (ctr, key, [hex(v) for v in got])
+    # vectorised over counters = scalar calls; the normal field is standard normal and a function of (seed, offset, index)
+    c0 = np.arange(5, dtype=np.uint64)
+    vec = philox_ref.philox4x32_10(c0, 0, 7, 1, 3, 9)
+    for i in range(5):
+        assert tuple(int(v[i]) for v in vec) == tuple(int(v) for v in philox_ref.philox4x32_10(i, 0, 7, 1, 3, 9))
+    n = philox_ref.normal_field(1234, 8, 1 << 18)
+    assert abs(n.mean()) < 4.0 / np.sqrt(n.size) and abs(n.var() - 1.0) < 4.0 * np.sqrt(2.0 / n.size)
+    assert abs((n ** 4).mean() - 3.0) < 0.1 and np.abs(n).max() < 6.0
+    assert np.array_equal(n[:1000], philox_ref.normal_field(1234, 8, 1000))
+    assert not np.array_equal(n[:1000], philox_ref.normal_field(1234, 12, 1000))
+    assert abs(np.corrcoef(n[:-1], n[1:])[0, 1]) < 0.01 and abs(np.corrcoef(n[:-4], n[4:])[0, 1]) < 0.01
 
 
 # ------------------------------------------------------------------ utils.py
@@ -479,6 +512,16 @@ loss_function = MixedLoss(LocalRenderer())            # main.py:82-89
 assert loss_function.rendering_loss.uses_fused_kernel() and loss_function.l1_weight == 0.1
 import dataset                                        # dataset.py:7 `import renderers` -> :206 renderers.LocalRenderer()
 assert dataset.renderers.LocalRenderer is LocalRenderer
+# the reference's OWN dataloader code reaches the patched renderer with its call shape (host [1,12,H,W] maps, tensor-valued
+# positions and colour, dataset.py:206-212): accepted up to the point where a GPU is needed, and on this GPU-less machine
+# the error names the way out (on an MI355X the call is served by K1: tests/test_gpu_parity.py)
+import torch
+class FakeSelf: use_augmentation = True
+try:
+    dataset.SvbrdfDataset.render_inputs(FakeSelf(), torch.rand(12, 16, 16), 2)
+    raise SystemExit("render_inputs computed something without a GPU")
+except amd.NativeLibraryError as e:
+    assert "patch_renderer=False" in str(e) and "no ROCm device" in str(e), e
 # patch_renderer=False: the reference keeps ITS LocalRenderer (CPU dataloader workers), the losses still fuse
 renderers.LocalRenderer = replaced["renderers.LocalRenderer"]
 amd.install(patch_renderer=False)
