@@ -13,15 +13,18 @@ self-spawned: ``python bench.py --gpus N``), batch sharded by rank, NO data-path
 path is embarrassingly parallel); the only collectives are the barrier, the MAX over ranks of the
 elapsed time and two small reporting reductions.
 
-`value` is measured with EVERY STEP ON ONE STREAM (the default, --streams 1): what a training loop,
-whose steps the optimizer serialises, gets from the loss.  The same run also times independent steps
-alternating on two HIP streams (one step's kernel fills the ramp and tail of the other's) and reports
-that beside the headline as `value_two_streams_overlapped` / `two_streams_overlapped` -- a property
-of a bench loop over independent batches, not of one training loop.
+ONE CLOCK for the headline (round 6): `value`, `ms_per_step` and `roofline.achieved / frac` all come from the same
+interval -- the wall time of the (median) timed region, MAX over ranks.  `value` is the TRAINING-LOOP figure: every step on
+one stream, ``loss.backward()`` through PyTorch's autograd engine, which is what a network output gets (one kernel launch
+per step: the engine is handed the cached device-resident 1.0, the node skips its scale launch).  Untimed follow-up legs
+of the same process report, beside it: the engine-free accumulate a LEAF input resolves to (`value_leaf_shortcut`), the
+three-launch form of rounds 1-4, independent steps alternating on two streams, the shader clock under the loop (cycles per
+launch), the copy bandwidth of this box (`copy_peak_GBps_measured`, svbrdf_debug_copy on 1 GiB) and the stand-alone
+rates of the HBM-bound kernels against it.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
 (HBM-bound accounting of the dominant kernel k_rendering_loss: algorithmic bytes
-144*H*W per patch / measured launch duration) and `cpu_baseline` (the eager-PyTorch
+144*H*W per patch / time per step of the timed region) and `cpu_baseline` (the eager-PyTorch
 restatement of the reference's algorithm, oracle/eager_torch.py, timed on this box's
 host cores on a bounded sample).
 """
@@ -31,11 +34,15 @@ import os
 import sys
 import time
 
+T_PROCESS_START = time.perf_counter()
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
+
+T_IMPORTED = time.perf_counter()
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_VALU_PEAK_TFLOPS = 157.3   # ditto, packed-FMA vector peak
@@ -52,6 +59,7 @@ def parse_args():
     ap.add_argument("--random-scenes", type=int, default=3)
     ap.add_argument("--specular-scenes", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-copy-peak", action="store_true", help="skip the 1 GiB copy-bandwidth leg (2 GiB of device memory)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the K1/K2 stand-alone rates (N=1 only)")
     ap.add_argument("--settle-ms", type=float, default=300.0,
                     help="untimed device settle phase before the W warm-up steps: the same step function is run for "
@@ -85,8 +93,13 @@ def parse_args():
     ap.add_argument("--bringup-timeout", type=float, default=60.0,
                     help="N > 1: seconds the rendezvous + communicator set-up + first all-reduce may take before the rank "
                          "prints a diagnosis (backend, devices, HSA_ENABLE_IPC_MODE_LEGACY, ...) and exits with code 3")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
-    ap.add_argument("--cpu-child", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--backward", default="engine", choices=("engine", "leaf"),
+                    help="how the timed region's loss.backward() runs: 'engine' (default) = through PyTorch's autograd engine, "
+                         "what a network output gets -- the training-loop figure; 'leaf' = the engine-free accumulate a plain "
+                         "backward() on a LEAF input resolves to on torch 2.10 (rounds 1-5's `value`); the other one is "
+                         "reported from an untimed follow-up leg either way")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget of the main leg (the probes, the "
+                    "one-thread figure and the C port add ~9 s)")
     ap.add_argument("--engine-threads", action="store_true",
                     help="keep PyTorch's multithreaded backward engine (default: run backward on the calling thread; "
                          "one process drives one GPU, the device-thread hop only adds wake-up latency)")
@@ -121,71 +134,53 @@ def _time_eager(threads, inp, tgt, table, budget_s, max_patches=400):
             return done / el, done, el
 
 
-def _all_cores_child(args, ncpu, limit_s=45.0):
-    """torch.set_num_threads(os.cpu_count()) in a child process with a hard time limit: on a 256-cpu host one eager
-    256x256 patch was measured to take minutes at 256 threads (oversubscription), so the figure is either the
-    rate or the statement that not even one patch finished within the limit."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", str(ncpu), "--size", str(args.size),
-           "--batch", "2", "--random-scenes", str(args.random_scenes), "--specular-scenes", str(args.specular_scenes)]
+def _cpu_model():
+    """first `model name` of /proc/cpuinfo ("core count and CPU model printed")"""
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s)
-        for line in r.stdout.splitlines():
-            if line.startswith("{"):
-                return json.loads(line)["patches_per_s"]
-        return "child failed: %s" % r.stderr[-200:]
-    except subprocess.TimeoutExpired:
-        return "< %.3f (no patch finished within %.0f s)" % (1.0 / limit_s, limit_s)
-
-
-def cpu_child(args):
-    """--cpu-child THREADS: times the eager port at that thread count on seeded inputs and prints one JSON line"""
-    from svbrdf_estimation_amd import losses, renderers
-    gen = torch.Generator().manual_seed(1234)
-    B = args.batch
-    inp, tgt = synthetic_maps(gen, B, args.size), synthetic_maps(gen, B, args.size)
-    fn = losses.RenderingLoss(renderers.LocalRenderer())
-    fn.random_configuration_count, fn.specular_configuration_count = args.random_scenes, args.specular_scenes
-    torch.manual_seed(313)
-    table = fn.sample_scene_table(B)
-    rate, done, el = _time_eager(args.cpu_child, inp, tgt, table, budget_s=5.0, max_patches=8)
-    print(json.dumps({"threads": args.cpu_child, "patches_per_s": rate, "patches": done, "seconds": el}), flush=True)
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def cpu_baseline(args, inp, tgt, table):
-    """Eager-PyTorch port of the reference's algorithm on the host cores (bounded sample).
-    Eager 256x256 elementwise ops do not scale to hundreds of threads, so a few thread
-    counts are tried briefly and the fastest is the reported baseline (cores = threads used)."""
+    """Eager-PyTorch port of the reference's algorithm on the host cores (bounded sample, ~20 s in all).
+    Eager 256x256 elementwise ops do not scale to hundreds of threads (at 256 threads one patch takes minutes:
+    oversubscription), so a few thread counts are probed briefly and the fastest is the reported baseline
+    (`cores` = threads used); every probed count is listed, the largest one also flat (`largest_probe_*`), and the
+    all-cores figure BASELINE.md section 3 words is given only when the host is small enough for it to be one of them."""
     ncpu = os.cpu_count() or 1
     cands = sorted({min(ncpu, c) for c in (4, 8, 16, 32)})
     probe = {}
     for c in cands:
-        probe[c] = _time_eager(c, inp, tgt, table, budget_s=1.5, max_patches=4)[0]
+        probe[c] = _time_eager(c, inp, tgt, table, budget_s=1.0, max_patches=4)[0]
         print("[bench] cpu probe threads=%d: %.2f patches/s" % (c, probe[c]), file=sys.stderr, flush=True)
     best = max(probe, key=probe.get)
     rate, done, el = _time_eager(best, inp, tgt, table, budget_s=args.cpu_seconds)
-    one, _, _ = _time_eager(1, inp, tgt, table, budget_s=3.0, max_patches=4)
-    every = probe[ncpu] if ncpu in probe else _all_cores_child(args, ncpu)
+    one, _, _ = _time_eager(1, inp, tgt, table, budget_s=2.0, max_patches=4)
     res = {"value": rate, "unit": "patches/s", "cores": best, "kind": "port",
-           # BASELINE.md section 3 words the baseline as torch.set_num_threads(os.cpu_count()): that figure, flat, beside
-           # `value` (= the best of a few thread counts; eager 256x256 elementwise ops do not scale to 256 threads)
-           "all_cores_threads": ncpu, "all_cores_patches_per_s": every,
-           "all_cores": {"threads": ncpu, "patches_per_s": every,
-                         "note": "torch.set_num_threads(os.cpu_count()) as BASELINE.md section 3 states it; eager "
-                                 "256x256 elementwise ops do not scale that far, so `value` is the best of a few counts"},
+           "cpu_model": _cpu_model(), "cpus": ncpu,
+           "probe_patches_per_s_by_threads": {str(c): probe[c] for c in cands},
+           "largest_probe_threads": cands[-1], "largest_probe_patches_per_s": probe[cands[-1]],
            "sample": "%d patches of %dx%d, S=%d, fwd+bwd, eager PyTorch restatement (oracle/eager_torch.py), "
                      "%.1f s, best of threads %s on a %d-cpu host" % (done, args.size, args.size, table.shape[1], el,
                                                                      cands, ncpu),
            "one_thread_patches_per_s": one}
-    try:   # the plain-C oracle (OpenMP), best of a few thread counts, for orientation
+    if ncpu in probe:       # torch.set_num_threads(os.cpu_count()) as BASELINE.md section 3 states it: only where it was run
+        res["all_cores_threads"], res["all_cores_patches_per_s"] = ncpu, probe[ncpu]
+    try:   # the plain-C oracle (OpenMP), best of two thread counts, for orientation
         from oracle import c_oracle
         a, b, c = inp[:2].numpy(), tgt[:2].numpy(), table[:2].numpy()
         best_c = (0.0, 0)
-        for th in sorted({min(ncpu, t) for t in (8, 32, 64)}):
+        for th in sorted({min(ncpu, t) for t in (8, 64)}):
             c_oracle.set_threads(th)
             c_oracle.rendering_loss(a, b, c)
             t0, reps = time.perf_counter(), 0
-            while time.perf_counter() - t0 < 1.5:
+            while time.perf_counter() - t0 < 1.0:
                 c_oracle.rendering_loss(a, b, c)
                 reps += 1
             best_c = max(best_c, (reps * 2 / (time.perf_counter() - t0), th))
@@ -236,38 +231,79 @@ def replayed_counters(library, B, H, S, record_path=None):
         return None, "NOT replayed: %r" % (e,), None
 
 
-def secondary_kernels(dev, H):
+def synthetic_maps_on_device(dev, seed, B, H, rough_min=0.0, tied=True):
+    """synthetic_maps' distribution, drawn by the device generator: for the untimed secondary legs, whose 288-map working
+    sets take seconds to draw on the host (the headline inputs stay host-drawn and seeded per rank)"""
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    n = torch.randn(B, 3, H, H, generator=gen, device=dev) * 0.3
+    n[:, 2] = 1.0 + n[:, 2].abs()
+    n = n / n.norm(dim=1, keepdim=True)
+    d = torch.rand(B, 3, H, H, generator=gen, device=dev)
+    r = torch.rand(B, 1 if tied else 3, H, H, generator=gen, device=dev).expand(B, 3, H, H) * (1.0 - rough_min) + rough_min
+    s = torch.rand(B, 3, H, H, generator=gen, device=dev)
+    return torch.cat((n, d, r, s), dim=1).contiguous()
+
+
+def _event_timed(fn, reps, dev, warm=3):
+    """average ms per call of `fn` over `reps` back-to-back calls, HIP events on the current stream (the launch stream)"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize(dev)
+    return a.elapsed_time(b) / reps
+
+
+def copy_peak(dev, gib=1.0):
+    """"report fraction of both nominal and measured-copy peak" -- the copy bandwidth of THIS box, measured in
+    this run: svbrdf_debug_copy (float4 streaming copy, non-temporal) on `gib` GiB -> `gib` GiB, far beyond the 256 MiB
+    Infinity Cache; bytes moved = read + written.  Best of three 10-launch regions."""
+    from svbrdf_estimation_amd import _native
+    n = int(gib * 2 ** 30) // 4
+    src = torch.empty(n, device=dev).uniform_(-1.0, 1.0)
+    dst = torch.empty_like(src)
+    ms = min(_event_timed(lambda: _native.debug_copy(dst, src), 10, dev) for _ in range(3))
+    ok = bool(torch.equal(src, dst))
+    del src, dst
+    return {"GBps": 8.0 * n / (ms * 1e-3) / 1e9, "ms_per_launch": ms, "bytes_moved_per_launch": 8.0 * n, "copied_correctly": ok,
+            "kernel": "svbrdf_debug_copy: k_copy_vec4<4, nontemporal>, %.0f MiB read + %.0f MiB written per launch"
+                      % (4.0 * n / 2 ** 20, 4.0 * n / 2 ** 20)}
+
+
+def secondary_kernels(dev, H, copy_gbps):
     """K1 / K2 alone at one render per map with a working set far beyond the 256 MiB Infinity Cache
-    (288 renders: 1.1 GB / 2.0 GB per launch): the HBM-bound kernels of the engine, for the record."""
+    (288 renders: 1.1 GB / 2.0 GB per launch): the HBM-bound kernels of the engine, for the record, against the nominal
+    8 TB/s and against the copy bandwidth measured in this run (`copy_gbps`)."""
     from svbrdf_estimation_amd import _native, environment
+
+    def hbm(gbps):
+        return {"algorithmic_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
+                "frac_of_measured_copy_peak": gbps / copy_gbps if copy_gbps else None}
     B = 288
-    gen = torch.Generator().manual_seed(7)
-    maps = synthetic_maps(gen, B, H).to(dev)
+    maps = synthetic_maps_on_device(dev, 7, B, H)
     torch.manual_seed(7)
     table = environment.BatchSceneSampler(B, 1, 0).sample().to(dev)
     cot = torch.randn(B, 1, 3, H, H, device=dev)
     out = {}
     for name, fn, nbytes in (("K1_render_fwd", lambda: _native.render_fwd(maps, table), 60.0 * H * H * B),
                              ("K2_render_bwd", lambda: _native.render_bwd(maps, table, cot), 108.0 * H * H * B)):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize(dev)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(10):
-            fn()
-        b.record()
-        torch.cuda.synchronize(dev)
-        ms = a.elapsed_time(b) / 10
-        gbps = nbytes / (ms * 1e-3) / 1e9
-        out[name] = {"renders_per_launch": B, "ms_per_launch": ms, "algorithmic_GBps": gbps,
-                     "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "renders_per_s": B / (ms * 1e-3)}
-    del maps, cot
+        ms = _event_timed(fn, 10, dev)
+        out[name] = dict({"renders_per_launch": B, "ms_per_launch": ms, "renders_per_s": B / (ms * 1e-3)},
+                         **hbm(nbytes / (ms * 1e-3) / 1e9))
+    # K1 with the sensor-noise epilogue (svbrdf_render_inputs: + sigma * N(0,1), clamp): one photo per map, same bytes
+    levels = torch.full((B, 1), 0.005, device=dev)
+    ms = _event_timed(lambda: _native.render_inputs(maps, table, levels, 1, 4), 10, dev)
+    out["K1_render_inputs_noise_clamp"] = dict({"photos_per_launch": B, "ms_per_launch": ms, "photos_per_s": B / (ms * 1e-3)},
+                                               **hbm(60.0 * H * H * B / (ms * 1e-3) / 1e9))
+    del maps, cot, levels
     # K3 alone (kernel-limited rates, SURVEY 8d): sensitivity to the roughness distribution at config 2, the
     # three-lobe path (independent roughness channels), and config 5 (512x512, 11 + 21 scenes)
     def k3(tag, B, Hk, n_random, n_specular, **kw):
-        g = torch.Generator().manual_seed(11)
-        a, t = synthetic_maps(g, B, Hk, **kw).to(dev), synthetic_maps(g, B, Hk, **kw).to(dev)
+        a, t = synthetic_maps_on_device(dev, 11, B, Hk, **kw), synthetic_maps_on_device(dev, 12, B, Hk, **kw)
         torch.manual_seed(11)
         tab = environment.BatchSceneSampler(B, n_random, n_specular).sample()
         tab = tab if B * (n_random + n_specular) <= _native.host_scenes_max_rows() else tab.to(dev)
@@ -296,8 +332,8 @@ def secondary_kernels(dev, H):
                     "patches_per_s": B / (ms * 1e-3), "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBPS}
     def k3_module(tag, B, Hk, loss_fn, n_streams):
         """whole steps through the module interface (host path, autograd), like the headline loop"""
-        g = torch.Generator().manual_seed(13)
-        sets = [(synthetic_maps(g, B, Hk).to(dev).requires_grad_(True), synthetic_maps(g, B, Hk).to(dev)) for _ in range(4)]
+        sets = [(synthetic_maps_on_device(dev, 13 + 2 * q, B, Hk).requires_grad_(True), synthetic_maps_on_device(dev, 14 + 2 * q, B, Hk))
+                for q in range(4)]
         sts = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else None
         torch.cuda.synchronize(dev)
 
@@ -331,9 +367,8 @@ def secondary_kernels(dev, H):
     # host-bound: us_per_call is host time.
     R = renderers.LocalRenderer()
     scene = environment.Scene(environment.Camera([0.1, -0.2, 2.0]), environment.Light([0.4, 0.3, 1.5], [30.0, 30.0, 30.0]))
-    gen = torch.Generator().manual_seed(17)
     for tag, nb in (("LocalRenderer_render_one_map", 0), ("LocalRenderer_render_batch8", 8)):
-        m = synthetic_maps(gen, max(nb, 1), H).to(dev)
+        m = synthetic_maps_on_device(dev, 17 + nb, max(nb, 1), H)
         m = m if nb else m[0]
         cot = torch.randn(max(nb, 1), 3, H, H, device=dev)
         x = m.clone().requires_grad_(True)
@@ -361,29 +396,32 @@ def secondary_kernels(dev, H):
                          "host_us_per_call": 1e6 * host_s / n}
         res["maps_per_call"] = max(nb, 1)
         out[tag] = res
+    # the dataloader's call shape served on the GPU (round 6): a HOST [1,12,H,W] map in, a HOST photo out (dataset.py:206-212:
+    # pinned round trip around K1), PCIe-inclusive by construction
+    host_map = synthetic_maps_on_device(dev, 19, 1, H).cpu()
+    for _ in range(5):
+        R.render(scene, host_map)
+    t0, n = time.perf_counter(), 200
+    for _ in range(n):
+        R.render(scene, host_map)
+    dt = (time.perf_counter() - t0) / n
+    out["LocalRenderer_render_host_tensor"] = {
+        "renders_per_s": 1.0 / dt, "us_per_call": 1e6 * dt,
+        "note": "CPU tensor in, CPU tensor out (the reference dataloader's call): host copy into pinned memory, H2D, K1, D2H, "
+                "event wait, clone -- 3.0 MiB up and 0.75 MiB down over PCIe per call"}
     # K4 (material mixing, dataset.py:142-160) and the input-photo synthesis on K1 (dataset.py:162-221), per call
     Bm = 64
-    a, b = synthetic_maps(gen, Bm, H).to(dev), synthetic_maps(gen, Bm, H).to(dev)
+    a, b = synthetic_maps_on_device(dev, 21, Bm, H), synthetic_maps_on_device(dev, 22, Bm, H)
     alpha = torch.rand(Bm, device=dev) * 0.8 + 0.1
-    for _ in range(3):
-        _native.mix_materials(a, b, alpha)
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        _native.mix_materials(a, b, alpha)
-    e1.record()
-    torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / 20
-    gb = 144.0 * H * H * Bm / (ms * 1e-3) / 1e9
-    out["K4_mix_materials"] = {"samples_per_launch": Bm, "ms_per_launch": ms, "algorithmic_GBps": gb,
-                               "frac_of_hbm_peak": gb / HBM_PEAK_GBPS, "samples_per_s": Bm / (ms * 1e-3),
-                               "working_set_MiB": 36.0 * H * H * 4 * Bm / 2 ** 20}
+    ms = _event_timed(lambda: _native.mix_materials(a, b, alpha), 20, dev)
+    out["K4_mix_materials"] = dict({"samples_per_launch": Bm, "ms_per_launch": ms, "samples_per_s": Bm / (ms * 1e-3),
+                                    "working_set_MiB": 36.0 * H * H * 4 * Bm / 2 ** 20}, **hbm(144.0 * H * H * Bm / (ms * 1e-3) / 1e9))
     for views, Bs in ((1, 8), (5, 16)):
         sv = a[:Bs]
         for _ in range(3):
             synthesis.render_inputs(sv, views)
         torch.cuda.synchronize(dev)
+        launches = _native.launch_count()
         t0, n = time.perf_counter(), 30
         for _ in range(n):
             synthesis.render_inputs(sv, views)
@@ -391,7 +429,9 @@ def secondary_kernels(dev, H):
         dt = (time.perf_counter() - t0) / n
         out["render_inputs_B%d_views%d" % (Bs, views)] = {
             "photos_per_s": Bs * views / dt, "ms_per_call": 1e3 * dt,
-            "note": "scene draws on the host in the reference's order + one K1 launch + device noise + clamp, whole batch"}
+            "kernel_launches_per_call": (_native.launch_count() - launches) / n,
+            "note": "scene draws on the host in the reference's order + ONE launch of K1 with the noise + clamp epilogue "
+                    "(svbrdf_render_inputs_host_scenes), whole batch; host-bound on the per-sample scene draws"}
     del a, b
     mixed = losses.MixedLoss(renderers.LocalRenderer())
     # BASELINE configs[3]: batch 16, mixed loss (the multi-view network's output has the same loss shapes); its 144 scene
@@ -437,8 +477,6 @@ def plumbing_only(args, rank, world, placement):
 
 def main():
     args = parse_args()
-    if args.cpu_child:
-        return cpu_child(args)
     from svbrdf_estimation_amd import launch
     if args.gpus > 1 and not launch.launched_as_rank():
         # started as ONE plain process (`python bench.py --gpus N`): become the parent of N fresh rank processes.
@@ -562,6 +600,12 @@ def main():
 
     if not args.engine_threads:
         torch.autograd.set_multithreading_enabled(False)
+    # `value` is the training-loop figure: loss.backward() through PyTorch's autograd engine (what a network output gets; one
+    # kernel launch per step).  The engine-free accumulate a LEAF input resolves to is timed in a follow-up leg
+    # (value_leaf_shortcut); --backward leaf makes it the timed region instead (rounds 1-5's `value`).
+    shortcut_available = bool(losses._FAST_BACKWARD)
+    losses._FAST_BACKWARD = shortcut_available and args.backward == "leaf"
+    losses._UNIT_GRADIENT = True
     torch.cuda.synchronize(dev)               # inputs were produced on the default stream
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:      # untimed, see --settle-ms
@@ -721,67 +765,73 @@ def main():
     ns = main_ns
     other_ms = sorted(p[0].elapsed_time(p[1]) for p in ev_other if p is not None)
     other_ms_avg = sum(other_ms) / len(other_ms)
-    # two more untimed legs, one stream: `loss.backward()` through PyTorch's autograd engine instead of the engine-free
-    # accumulate a LEAF input gets (losses._FusedLossTensor).  A network output -- the training case -- always takes the
-    # engine, so this is the step rate of the loss as a node of a larger graph.  First as the product does it since round 5
-    # (the engine is handed the extension's cached device-resident 1.0 and the node skips its scale launch: one kernel per
-    # step), then with the engine's own ones-fill kernel and the node's no-op scale launch (rounds 1-4: three kernels).
+    # two more untimed legs, one stream: the OTHER way loss.backward() can run (the timed region took the engine with the unit
+    # gradient: one launch per step) -- the engine-free accumulate a LEAF input gets (losses._FusedLossTensor; torch 2.10 only),
+    # and the engine with its own ones-fill kernel and the node's no-op scale launch (rounds 1-4: three kernels per step).
     saved_ns, ns = ns, 0
-    saved_fast, losses._FAST_BACKWARD = losses._FAST_BACKWARD, False
-    engine_steps = max(600, other_steps)
-    engine_ms = {}
-    for unit in (False, True):
-        losses._UNIT_GRADIENT = unit
+    timed_fast = bool(losses._FAST_BACKWARD)
+    leg_steps = max(600, other_steps)
+
+    def backward_mode_leg(fast, unit):
+        losses._FAST_BACKWARD, losses._UNIT_GRADIENT = fast, unit
         t_settle = time.perf_counter()
         while time.perf_counter() - t_settle < 20e-3:       # past the clock sag that follows the synchronize above (section 4.4)
             for _ in range(32):
                 step()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(dev))           # no synchronize in front: the loop keeps running into the timed steps
-        for _ in range(engine_steps):
+        for _ in range(leg_steps):
             step()
         e1.record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
-        engine_ms[unit] = e0.elapsed_time(e1) / engine_steps
-    losses._UNIT_GRADIENT = True
-    engine_ms_per_step, engine_plain_ms_per_step = engine_ms[True], engine_ms[False]
-    losses._FAST_BACKWARD, ns = saved_fast, saved_ns
+        return e0.elapsed_time(e1) / leg_steps
+    leaf_ms_per_step = backward_mode_leg(True, True) if shortcut_available else None
+    engine_ms_per_step = backward_mode_leg(False, True)
+    engine_plain_ms_per_step = backward_mode_leg(False, False)
+    losses._FAST_BACKWARD, losses._UNIT_GRADIENT, ns = timed_fast, True, saved_ns
+
+    # the copy bandwidth of this box, measured in this run (rank 0's GPU; untimed leg)
+    copy = None
+    if rank == 0 and not args.no_copy_peak:
+        try:
+            copy = copy_peak(dev)
+        except Exception as e:  # pragma: no cover
+            copy = {"GBps": None, "error": repr(e)}
 
     if rank == 0:
         patches = world * B * args.steps
-        ms_per_step = 1e3 * elapsed / args.steps
+        ms_per_step = 1e3 * elapsed / args.steps      # THE interval of the headline: value, roofline.achieved and frac
         alg_bytes = 144.0 * H * H * B                 # per launch: 36 planes x 4 B per patch
         n_streams = max(1, main_ns)
+        follow_up = "follow-up leg of rank 0, same process and tensors, right after the timed region"
         # the two ways of issuing the steps, whichever of them was the timed region
         if main_ns == 0:
             one = {"ms_per_step": ms_per_step, "kernel_ms": kernel_ms, "steps": args.steps, "leg": "the timed region"}
-            two = {"ms_per_step": other_ms_per_step, "kernel_ms": other_ms, "steps": other_steps, "streams": 2,
-                   "leg": "follow-up leg of rank 0, same process and tensors, right after the timed region"}
+            two = {"ms_per_step": other_ms_per_step, "kernel_ms": other_ms, "steps": other_steps, "streams": 2, "leg": follow_up}
         else:
-            one = {"ms_per_step": other_ms_per_step, "kernel_ms": other_ms, "steps": other_steps,
-                   "leg": "follow-up leg of rank 0, same process and tensors, right after the timed region"}
+            one = {"ms_per_step": other_ms_per_step, "kernel_ms": other_ms, "steps": other_steps, "leg": follow_up}
             two = {"ms_per_step": ms_per_step, "kernel_ms": kernel_ms, "steps": args.steps, "streams": main_ns,
                    "leg": "the timed region"}
         one_kernel_avg = sum(one["kernel_ms"]) / len(one["kernel_ms"])
         two_kernel_avg = sum(two["kernel_ms"]) / len(two["kernel_ms"])
-        # time one launch takes out of the timed region.  With one stream that is the launch's own event-bracketed
-        # duration; with N streams launches overlap (each takes longer, event-bracketed, than its share of the GPU), so
-        # the share is what the roofline is priced with: timed region / launches (host-bound gaps count against the kernel).
-        share_ms = ms_per_step if n_streams > 1 else region_ms_per_launch
-        achieved = alg_bytes / (share_ms * 1e-3) / 1e9
-        # one launch at a time: the region events of a single-stream timed region; in a follow-up leg (no region pair) the
-        # leg's wall time per step, which on one stream bounds the launch duration from above
-        one_launch_ms = region_ms_per_launch if main_ns == 0 else one["ms_per_step"]
-        achieved_one = alg_bytes / (one_launch_ms * 1e-3) / 1e9
+        # ONE clock: the roofline is priced with the interval `value` is priced with (wall time of the median region, MAX
+        # over ranks, / steps): frac x peak x ms_per_step / bytes == 1.  What rounds 1-5 priced it with -- the HIP event
+        # pair around the region on the launch stream / launches, 2-3 % shorter (no barrier, no synchronize, no host tail) --
+        # stays beside it as time_per_launch_ms / frac_by_launch_events.
+        achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9
+        events_ms = region_ms_per_launch if n_streams == 1 else None
+        achieved_events = alg_bytes / (events_ms * 1e-3) / 1e9 if events_ms else None
         achieved_two = alg_bytes / (two["ms_per_step"] * 1e-3) / 1e9
+        copy_gbps = copy.get("GBps") if copy else None
         valu_issue = None
         traffic, traffic_source, tj = replayed_counters(_native.library_path(), B, H, S)
+        cycle_ms = cycle_leg_ms or events_ms or ms_per_step
         if tj is not None and tj.get("valu_wave_instr_per_launch") and clock_ghz:
             # what actually bounds K3: wave64 VALU instructions issued (PMC SQ_INSTS_VALU of the same
             # kernel, profiles/) against the SIMD-32 issue peak of one per 2 cycles per SIMD
-            # (MI355X_MICROARCH.md), 1024 SIMDs, at the clock the chip holds under the timed region's loop
+            # (MI355X_MICROARCH.md), 1024 SIMDs, at the clock the chip holds under the loop
             peak = 1024 * clock_ghz * 1e9 / 2.0
-            rate = tj["valu_wave_instr_per_launch"] / ((cycle_leg_ms or share_ms) * 1e-3)   # duration of the clock's interval
+            rate = tj["valu_wave_instr_per_launch"] / (cycle_ms * 1e-3)      # duration of the clock's own interval
             valu_issue = {"wave_instr_per_launch": tj["valu_wave_instr_per_launch"],
                           "of_which_transcendental": tj.get("trans_wave_instr_per_launch"),
                           "instr_count_source": traffic_source,
@@ -794,15 +844,24 @@ def main():
                               if tj.get("trans_wave_instr_per_launch") else None,
                           "clock_GHz_under_load": clock_ghz, "clock_source": clock_note}
         working_set = len(batches) * (2 * 12 + 12) * H * H * B * 4
+        timed_is = ("loss.backward() through PyTorch's autograd engine (what a network output gets: the training-loop figure; one "
+                    "kernel launch per step)" if not timed_fast else
+                    "the engine-free accumulate a plain loss.backward() on a LEAF input resolves to (--backward leaf)")
+        value_leaf = world * B / (leaf_ms_per_step * 1e-3) if leaf_ms_per_step else None
+        value_engine = patches / elapsed if not timed_fast else world * B / (engine_ms_per_step * 1e-3)
         out = {
             "metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)",
             "value": patches / elapsed, "unit": "patches/s", "n_gpus": world,
             "per_gpu_value": patches / elapsed / world,
-            "value_through_autograd_engine": world * B / (engine_ms_per_step * 1e-3),
+            "value_is": timed_is,
+            # the same figure under its round-5 name (then a follow-up leg; since round 6 it IS the timed region)
+            "value_through_autograd_engine": value_engine,
+            "value_leaf_shortcut": value_leaf if not timed_fast else patches / elapsed,
             "value_through_autograd_engine_with_fill_and_scale_launches": world * B / (engine_plain_ms_per_step * 1e-3),
             "valu_issue_frac": valu_issue["frac"] if valu_issue else None,      # what bounds K3 (also in roofline, with its inputs)
             "value_single_stream": world * B / (one["ms_per_step"] * 1e-3),
             "value_two_streams_overlapped": world * B / (two["ms_per_step"] * 1e-3),
+            "copy_peak_GBps_measured": copy_gbps,
             "timed_regions": {"count": n_regions, "steps_each": args.steps, "median_index": median_region,
                               "ms_per_step": [1e3 * e / args.steps for e in job_elapsed],
                               "value": [world * B * args.steps / e for e in job_elapsed],
@@ -812,13 +871,13 @@ def main():
                                       "one region (the form with >= 256 steps)"},
             "value_note": (("`value` = the MEDIAN of %d consecutive timed regions of %d steps each (all listed in timed_regions); "
                             % (n_regions, args.steps)) if n_regions > 1 else "") +
-                          (("`value` = the timed region, every step on ONE stream (what a training loop, serialised by its "
-                            "optimizer, gets); value_two_streams_overlapped = independent steps alternating on two streams, %s"
-                            % two["leg"]) if main_ns == 0 else
-                           ("`value` = the timed region with --streams %d: independent steps overlap on the GPU; "
-                            "value_single_stream = %s" % (main_ns, one["leg"]))) +
-                          "; value_through_autograd_engine = the same step when the loss is a node of a larger graph (a network "
-                          "output: the training case)",
+                          "`value` = patches / wall time of the timed region: every step on %s, %s.  roofline.achieved and "
+                          "roofline.frac are priced with the same interval (ms_per_step).  Untimed follow-up legs of the same "
+                          "process: value_leaf_shortcut = %s; value_two_streams_overlapped = independent steps alternating on "
+                          "two streams (a bench-loop property, not a training loop's)"
+                          % ("ONE stream" if main_ns == 0 else "%d streams" % main_ns, timed_is,
+                             "the engine-free accumulate of a LEAF input (rounds 1-5's `value`)" if not timed_fast else
+                             "this region itself (see value_through_autograd_engine for the engine)"),
             "ranks_seen": ranks_seen,       # summed by the bring-up all-reduce itself, not read from the environment
             "process_group": ("%s (%s), world size %d" % (args.backend, "RCCL" if nccl else "CPU transport, plumbing only",
                                                           dist.get_world_size())) if dist is not None else None,
@@ -836,18 +895,52 @@ def main():
                        "global_batch": world * B, "H": H, "W": H, "scenes": S,
                        "parallelism": "batch-sharded x%d, no data-path collective" % world,
                        "streams_per_gpu": n_streams,
-                       "step_issue": ("step k (launch + backward) is issued on HIP stream k mod %d: the steps are independent "
-                                      "batches, so one step's kernel fills the ramp and tail of the other's" % n_streams)
-                                     if n_streams > 1 else "every step on one stream",
+                       "backward": "autograd engine" if not timed_fast else "leaf shortcut",
                        "distinct_batches": len(batches),
                        "working_set_MiB": working_set / 2.0 ** 20,
                        "working_set_note": "input + target + gradient of every batch visited round-robin; the Infinity "
                                            "Cache holds 256 MiB"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "time_per_step_ms": ms_per_step,          # = ms_per_step: the interval achieved / frac are priced with
+                         "achieved_definition": "algorithmic bytes per launch (144*H*W*B) / ms_per_step of the (median) timed "
+                                                "region -- the interval `value` is priced with; one launch per step",
+                         # secondary: the HIP event pair around the same region on the launch stream / launches (rounds 1-5's
+                         # pricing; excludes the barrier / synchronize / host tail of the region: 2-3 % shorter)
+                         "time_per_launch_ms": events_ms,
+                         "frac_by_launch_events": achieved_events / HBM_PEAK_GBPS if achieved_events else None,
+                         # against the copy bandwidth this box reached in this run (svbrdf_debug_copy, 1 GiB each way)
+                         "copy_peak_GBps_measured": copy_gbps,
+                         "frac_of_measured_copy_peak": achieved / copy_gbps if copy_gbps else None,
+                         "copy_peak": copy,
+                         # flat copies of what the nested objects below hold (a line parser that keeps scalars keeps these)
+                         "valu_issue_frac": valu_issue["frac"] if valu_issue else None,
+                         "valu_issue_clock_GHz": valu_issue["clock_GHz_under_load"] if valu_issue else None,
+                         # boxes (and builds: the chip lowers its clock as the issue stream gets denser) differ in clock by
+                         # 5-15 %; launch duration x the clock measured in this run is the box-independent figure
+                         "shader_cycles_per_launch": (cycle_ms * 1e-3 * clock_ghz * 1e9) if clock_ghz else None,
+                         "shader_cycles_leg_ms_per_launch": cycle_leg_ms,    # the interval the clock was read in (untimed follow-up leg)
+                         "valu_issue_wave_instr_per_launch": valu_issue["wave_instr_per_launch"] if valu_issue else None,
+                         "kernel": "%s<GRAD=true,L1=false,HEAD=false> (single launch: both shadings, log/L1, adjoint, loss finalise)"
+                                   % ("k_rendering_loss_inl" if B * S <= _native.host_scenes_max_rows() else "k_rendering_loss"),
+                         "scene_table": "by value in the kernel-argument block (no H2D command)"
+                                        if B * S <= _native.host_scenes_max_rows() else "pinned-ring upload",
+                         "launches_in_flight": n_streams,
+                         # event pairs around a SAMPLE of single launches (dispatch gap + kernel + event bubble each): evidence
+                         # that a launch is what fills a step, never what the roofline is priced with
+                         "kernel_launches_timed": len(kernel_ms),
+                         "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
+                         "kernel_ms_note": "pairs bracket every 32nd launch of the timed region (a region shorter than 256 steps: "
+                                           "every 16th of an untimed 512-step leg right after it); a pair spans the ~3 us dispatch "
+                                           "gap in front of the launch and its own end-of-pipe bubble, so it reads longer than "
+                                           "ms_per_step",
+                         "valu_frac_of_fp32_peak": (FLOP_PER_PIXEL_SCENE * H * H * S * B / (ms_per_step * 1e-3))
+                                                   / (FP32_VALU_PEAK_TFLOPS * 1e12),
+                         "valu_issue": valu_issue},
             "single_stream": {"patches_per_s": B / (one["ms_per_step"] * 1e-3), "ms_per_step": one["ms_per_step"],
                               "kernel_ms_avg": one_kernel_avg, "kernel_ms_median": one["kernel_ms"][len(one["kernel_ms"]) // 2],
-                              "kernel_launches_timed": len(one["kernel_ms"]), "steps": one["steps"], "leg": one["leg"],
-                              "note": "per GPU: every step on one stream, events around a sample of the launches -- the "
-                                      "duration rocprofv3 --kernel-trace reports for `bench.py --streams 1`"},
+                              "kernel_launches_timed": len(one["kernel_ms"]), "steps": one["steps"], "leg": one["leg"]},
             "two_streams_overlapped": {"patches_per_s": B / (two["ms_per_step"] * 1e-3), "ms_per_step": two["ms_per_step"],
                                        "streams": two["streams"], "kernel_ms_avg_while_overlapped": two_kernel_avg,
                                        "steps": two["steps"], "leg": two["leg"],
@@ -855,71 +948,37 @@ def main():
                                        "note": "per GPU: step k (launch + backward) on stream k mod 2; the steps are independent "
                                                "batches, so one step's kernel fills the ramp and tail of the other's.  A "
                                                "bench-loop property: not what one training loop gets"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "frac_single_launch": achieved_one / HBM_PEAK_GBPS,
-                         # flat copies of what the nested objects below hold (a line parser that keeps scalars keeps these)
-                         "valu_issue_frac": valu_issue["frac"] if valu_issue else None,
-                         "valu_issue_clock_GHz": valu_issue["clock_GHz_under_load"] if valu_issue else None,
-                         # boxes (and builds: the chip lowers its clock as the issue stream gets denser) differ in clock by
-                         # 5-15 %; launch duration x the clock measured in this run is the box-independent figure
-                         "shader_cycles_per_launch": ((cycle_leg_ms or share_ms) * 1e-3 * clock_ghz * 1e9) if clock_ghz else None,
-                         "shader_cycles_leg_ms_per_launch": cycle_leg_ms,    # the interval the clock was read in (untimed follow-up leg)
-                         "valu_issue_wave_instr_per_launch": valu_issue["wave_instr_per_launch"] if valu_issue else None,
-                         "patches_per_s_through_autograd_engine": B / (engine_ms_per_step * 1e-3),
-                         "consistent_time_per_launch_le_ms_per_step": bool(share_ms <= ms_per_step * 1.0001),
-                         "sampled_pair_minus_time_per_launch_us": 1e3 * (one_kernel_avg - one_launch_ms),
-                         "achieved_definition": ("algorithmic bytes per launch / time per launch in the timed region "
-                                                 "(timed region / launches: launches on %d streams overlap)" % n_streams)
-                                                if n_streams > 1 else
-                                                "algorithmic bytes per launch / average launch duration = HIP events around the "
-                                                "timed region on the launch stream / launches (back-to-back launches on one stream)",
-                         "time_per_launch_ms": share_ms,
-                         "one_launch_alone": {"achieved": achieved_one, "frac": achieved_one / HBM_PEAK_GBPS,
-                                              "ms_per_launch": one_launch_ms, "sampled_event_pairs_ms_avg": one_kernel_avg},
-                         "frac_of_measured_copy_peak": achieved / 6290.0,   # MI355X_MICROARCH.md: float4 copy
-                         "kernel": "%s<GRAD=true,L1=false,HEAD=false> (single launch: both shadings, log/L1, adjoint, loss finalise)"
-                                   % ("k_rendering_loss_inl" if B * S <= _native.host_scenes_max_rows() else "k_rendering_loss"),
-                         "scene_table": "by value in the kernel-argument block (no H2D command)"
-                                        if B * S <= _native.host_scenes_max_rows() else "pinned-ring upload",
-                         "kernel_limited_patches_per_s": B / (share_ms * 1e-3),
-                         "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
-                         "kernel_ms_note": "a sampled event PAIR spans dispatch gap (~3 us) + kernel + event bubble: exceeds time_per_launch_ms by design.  "
-                                           "Pairs bracket a SAMPLE of the launches (every 32nd of the timed region; for a region "
-                                           "shorter than 256 steps: every 16th of an untimed 512-step leg right after it).  A pair on a "
-                                           "back-to-back stream spans the launch AND the ~3 us dispatch gap in front of it plus its own "
-                                           "end-of-pipe bubble, so it reads longer than time_per_launch_ms (and than ms_per_step); "
-                                           "with N > 1 streams a launch overlaps its neighbours and exceeds time_per_launch_ms.  The "
-                                           "roofline is priced with time_per_launch_ms (<= ms_per_step: consistent_... above)",
-                         "launches_in_flight": n_streams,
-                         "kernel_launches_timed": len(kernel_ms),
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "valu_frac_of_fp32_peak": (FLOP_PER_PIXEL_SCENE * H * H * S * B / (share_ms * 1e-3))
-                                                   / (FP32_VALU_PEAK_TFLOPS * 1e12),
-                         "valu_issue": valu_issue},
-            "single_stream_through_autograd_engine": {
-                "patches_per_s": B / (engine_ms_per_step * 1e-3), "ms_per_step": engine_ms_per_step, "steps": engine_steps,
-                "patches_per_s_with_fill_and_scale_launches": B / (engine_plain_ms_per_step * 1e-3),
-                "note": "per GPU, follow-up legs: the same step with loss.backward() going through PyTorch's autograd engine -- what "
-                        "the loss costs as a node of a larger graph (a network output).  Since round 5 a plain loss.backward() hands "
-                        "the engine the extension's cached device-resident 1.0 and the node, recognising it by address, skips its "
-                        "scale launch: one kernel per step (patches_per_s); with the engine's own ones-fill kernel and the node's "
-                        "no-op scale launch, as in rounds 1-4: three (patches_per_s_with_fill_and_scale_launches).  `value` uses "
-                        "the engine-free accumulate that a plain loss.backward() on a LEAF input resolves to (%s)" % (
-                            "enabled" if saved_fast else "disabled on this torch version")},
+            "backward_modes": {
+                "timed_region": "engine" if not timed_fast else "leaf shortcut",
+                "engine_one_launch_per_step": {"patches_per_s": B / (engine_ms_per_step * 1e-3), "ms_per_step": engine_ms_per_step},
+                "engine_with_fill_and_scale_launches": {"patches_per_s": B / (engine_plain_ms_per_step * 1e-3),
+                                                        "ms_per_step": engine_plain_ms_per_step},
+                "leaf_shortcut": {"patches_per_s": B / (leaf_ms_per_step * 1e-3), "ms_per_step": leaf_ms_per_step}
+                                 if leaf_ms_per_step else "not available on this torch version",
+                "steps_each": leg_steps,
+                "note": "per GPU, untimed follow-up legs on one stream, HIP events around each.  engine_one_launch_per_step: the "
+                        "engine is handed the extension's cached device-resident 1.0 and the node, recognising it by address and "
+                        "version, skips its scale launch (the timed region's mode by default); ..._with_fill_and_scale_launches: "
+                        "the engine's own ones-fill kernel and the node's no-op scale launch, as in rounds 1-4 (three kernels); "
+                        "leaf_shortcut: input.grad (+)= the buffer the kernel wrote, no engine (a LEAF input only: the notebooks' "
+                        "direct map optimisation, rounds 1-5's bench loop)"},
             "loss": mean_loss,
             "host_path": "native C++ extension (csrc/host_ext.cpp)" if ext is not None else "python + ctypes",
             "autograd_engine": "multithreaded" if args.engine_threads else "calling thread",
             "settle_ms": args.settle_ms,
         }
+        t_main = time.perf_counter()
         if world == 1 and not args.no_secondary:
-            out["secondary"] = secondary_kernels(dev, H)
+            out["secondary"] = secondary_kernels(dev, H, copy_gbps)
+        t_secondary = time.perf_counter()
         if world == 1 and not args.no_cpu_baseline:
             os.sched_setaffinity(0, host_cpus)      # "the host cores of the box", not the GPU's socket only
             table = loss_fn.sample_scene_table(B)
             out["cpu_baseline"] = cpu_baseline(args, inp_h, tgt_h, table)
         else:
             out["cpu_baseline"] = None
+        out["wall_s"] = {"imports_to_main": T_IMPORTED - T_PROCESS_START, "gpu_legs": t_main - T_IMPORTED,
+                         "secondary": t_secondary - t_main, "cpu_baseline": time.perf_counter() - t_secondary}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -270,8 +270,25 @@ struct State {
     int device = -1;
     // the device-resident upstream gradient 1.0 that `loss.backward()` is given instead of letting the engine fill a fresh
     // ones tensor (unit_gradient below); the node recognises it by address and skips its scale launch
+    // It is handed to Python (and through the engine to any hook on the loss), so "this is 1.0" is only believed while the
+    // tensor's version counter still reads what it read at creation: an in-place edit (a loss-scaling hook doing
+    // g.mul_(k)) keeps the address but bumps the version -- the node then applies the scale like for any other gradient,
+    // and the next backward gets a fresh 1.0 (ensure_unit_grad).  Created with the workspace at the first forward on a
+    // device, i.e. outside any later stream capture.
     at::Tensor unit_grad;
     std::atomic<const void *> unit_ptr{nullptr};
+    std::atomic<uint32_t> unit_version{0};
+
+    // under `mu`
+    void ensure_unit_grad(const at::TensorOptions &like)
+    {
+        if (unit_grad.defined() && unit_grad.device() == like.device() && unit_grad._version() == unit_version.load(std::memory_order_relaxed))
+            return;
+        unit_ptr.store(nullptr, std::memory_order_relaxed);
+        unit_grad = at::ones({}, like.dtype(at::kFloat).requires_grad(false));
+        unit_version.store(unit_grad._version(), std::memory_order_relaxed);
+        unit_ptr.store(unit_grad.data_ptr(), std::memory_order_relaxed);
+    }
 };
 // Deliberately never destroyed: the state owns device tensors, pinned host slots and events, and a static
 // destructor would release them AFTER the HIP runtime has shut down at interpreter exit (observed: a process that
@@ -354,7 +371,9 @@ struct FusedLossBackward : public torch::autograd::Node {
         // A plain `loss.backward()` arrives here with THE unit gradient (losses._FusedLossTensor.backward hands the engine
         // the cached device-resident 1.0 of unit_gradient() instead of letting it fill a fresh ones tensor): recognised by
         // address, it needs no scaling at all -- the step is then ONE kernel launch, as on the engine-free leaf path.
-        const bool unit = g0.is_cuda() && g0.data_ptr() == g_state.unit_ptr.load(std::memory_order_relaxed);
+        // (address AND version counter: a hook that edited the tensor in place keeps the address; then it is a scale like any)
+        const bool unit = g0.is_cuda() && g0.data_ptr() == g_state.unit_ptr.load(std::memory_order_relaxed) &&
+                          g0._version() == g_state.unit_version.load(std::memory_order_relaxed);
         torch::autograd::variable_list out(2);
         at::AutoDispatchBelowADInplaceOrView below_autograd;
         if (has_in) {
@@ -462,6 +481,7 @@ void ensure_device_state(const at::Tensor &input, int S, int64_t stream)
         xr = host.to(input.device());
     }
     g_state.xrow = xr;
+    g_state.ensure_unit_grad(input.options());
 }
 
 void check_inputs(const at::Tensor &input, const at::Tensor &target, bool head)
@@ -658,17 +678,15 @@ bool fast_backward(const at::Tensor &loss, const at::Tensor &input, int64_t curr
     return true;
 }
 
-// The upstream gradient of a plain `loss.backward()`: a 0-dim float32 1.0 on the loss's device, created once per device and
-// never written again.  Handing it to torch.autograd.backward as the explicit gradient saves the engine's fill kernel, and
+// The upstream gradient of a plain `loss.backward()`: a 0-dim float32 1.0 on the loss's device, created once per device
+// (with the workspace, at the first forward) and never written by this extension; callers must not write it either -- if
+// one does, the version counter gives it away (State::ensure_unit_grad).  Handing it to torch.autograd.backward as the explicit gradient saves the engine's fill kernel, and
 // FusedLossBackward::apply recognises it by address and skips its own (no-op) scale launch.
 at::Tensor unit_gradient(const at::Tensor &loss)
 {
     TORCH_CHECK(loss.is_cuda() && loss.scalar_type() == at::kFloat, "unit_gradient: the loss must be a float32 device tensor");
     std::lock_guard<std::mutex> lock(g_state.mu);
-    if (!g_state.unit_grad.defined() || g_state.unit_grad.device() != loss.device()) {
-        g_state.unit_grad = at::ones({}, loss.options().requires_grad(false));
-        g_state.unit_ptr.store(g_state.unit_grad.data_ptr(), std::memory_order_relaxed);
-    }
+    g_state.ensure_unit_grad(loss.options());      // normally a no-op (made with the workspace); a mutated one is replaced
     return g_state.unit_grad;
 }
 

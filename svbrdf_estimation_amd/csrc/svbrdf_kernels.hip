@@ -1563,23 +1563,27 @@ __global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *__restri
 
 // ------------------------------------------------------------------------------------------
 // measurement aid: the HBM copy rate of THIS box ("fraction of both nominal and measured-copy peak").  A plain
-// streaming copy, 16 bytes per lane and access, non-temporal both ways, kCopyUnroll independent loads in flight per lane
-// before the first store; a workgroup owns one contiguous 16 KiB chunk.  Bytes moved = 2 x n x 4.
+// streaming copy, 16 bytes per lane and access, non-temporal both ways, UNROLL independent loads in flight per lane
+// before the first store; a workgroup owns one contiguous UNROLL x 4 KiB chunk.  Bytes moved = 2 x n x 4.
+// (SVBRDF_COPY_UNROLL / SVBRDF_COPY_NT select the A/B variants of tools/copy_peak.py; shipped: see svbrdf_debug_copy.)
 // ------------------------------------------------------------------------------------------
-constexpr int kCopyUnroll = 4;
+template <int UNROLL, bool NT>
 __global__ __launch_bounds__(kThreads) void k_copy_vec4(vec4f *__restrict__ dst, const vec4f *__restrict__ src, size_t n4)
 {
-    const size_t base = (size_t)blockIdx.x * (kThreads * kCopyUnroll) + threadIdx.x;
-    vec4f v[kCopyUnroll];
+    const size_t base = (size_t)blockIdx.x * (kThreads * UNROLL) + threadIdx.x;
+    vec4f v[UNROLL];
 #pragma unroll
-    for (int u = 0; u < kCopyUnroll; ++u) {
+    for (int u = 0; u < UNROLL; ++u) {
         const size_t i = base + (size_t)u * kThreads;
-        if (i < n4) v[u] = __builtin_nontemporal_load(src + i);
+        if (i < n4) v[u] = NT ? __builtin_nontemporal_load(src + i) : src[i];
     }
 #pragma unroll
-    for (int u = 0; u < kCopyUnroll; ++u) {
+    for (int u = 0; u < UNROLL; ++u) {
         const size_t i = base + (size_t)u * kThreads;
-        if (i < n4) __builtin_nontemporal_store(v[u], dst + i);
+        if (i < n4) {
+            if (NT) __builtin_nontemporal_store(v[u], dst + i);
+            else dst[i] = v[u];
+        }
     }
 }
 
@@ -2058,10 +2062,22 @@ int svbrdf_debug_copy(float *dst, const float *src, size_t n, void *stream)
     if (!dst || !src) return fail(SVBRDF_ERR_NULL, "debug_copy: null pointer");
     if (n == 0 || (n & 3) != 0) return fail(SVBRDF_ERR_DIMS, "debug_copy: n must be a positive multiple of 4 floats");
     if (!aligned(dst, 16) || !aligned(src, 16)) return fail(SVBRDF_ERR_ALIGN, "debug_copy: pointers must be 16-byte aligned");
-    const size_t n4 = n / 4, per_block = (size_t)kThreads * kCopyUnroll, blocks = (n4 + per_block - 1) / per_block;
+    const int unroll = [] { const char *e = std::getenv("SVBRDF_COPY_UNROLL"); const int v = e ? std::atoi(e) : 0;
+                            return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4; }();
+    const bool nt = [] { const char *e = std::getenv("SVBRDF_COPY_NT"); return !(e && e[0] == '0'); }();
+    const size_t n4 = n / 4, per_block = (size_t)kThreads * unroll, blocks = (n4 + per_block - 1) / per_block;
     if (blocks > 0x7fffffffULL) return fail(SVBRDF_ERR_DIMS, "debug_copy: n too large");
-    hipLaunchKernelGGL(k_copy_vec4, dim3((unsigned)blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<vec4f *>(dst), reinterpret_cast<const vec4f *>(src), n4);
+    const dim3 grid((unsigned)blocks), block(kThreads);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    vec4f *d = reinterpret_cast<vec4f *>(dst);
+    const vec4f *sp = reinterpret_cast<const vec4f *>(src);
+#define SVBRDF_COPY(U)                                                                            \
+    do {                                                                                          \
+        if (nt) hipLaunchKernelGGL((k_copy_vec4<U, true>), grid, block, 0, st, d, sp, n4);        \
+        else hipLaunchKernelGGL((k_copy_vec4<U, false>), grid, block, 0, st, d, sp, n4);          \
+    } while (0)
+    if (unroll == 8) SVBRDF_COPY(8); else if (unroll == 4) SVBRDF_COPY(4); else if (unroll == 2) SVBRDF_COPY(2); else SVBRDF_COPY(1);
+#undef SVBRDF_COPY
     return launch_status("debug_copy launch");
 }
 

@@ -159,7 +159,9 @@ class _FusedLossTensor(torch.Tensor):
             if leaf is not None and _FAST_BACKWARD and not retain_graph and inputs is None:
                 if ext.fast_backward(inner, leaf, _native._raw_stream(leaf.device)):
                     return None
-            if _UNIT_GRADIENT:
+            # not when someone watches the loss's gradient (a hook, retain_grad): they get the engine's own fresh ones
+            # tensor, theirs to edit; the node then sees an ordinary gradient and applies it
+            if _UNIT_GRADIENT and self._backward_hooks is None and not self.retains_grad:
                 gradient = ext.unit_gradient(inner)
         return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs)
 

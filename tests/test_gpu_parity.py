@@ -1423,6 +1423,38 @@ def test_leaf_backward_shortcut_equals_the_autograd_engine(dev, golden):
     ext = _hostext.module()
     u = ext.unit_gradient(engine[0].detach())
     assert u.item() == 1.0 and u.data_ptr() == ext.unit_gradient(engine[0].detach()).data_ptr() and not u.requires_grad
+    # ... and by VERSION: a loss-scaling hook that edits the incoming gradient in place keeps the address.  A hooked loss is
+    # given the engine's own ones tensor (the hook may do what it likes with it); the cached 1.0 itself, edited in place by
+    # whoever got hold of it, is not believed (the scale is applied) and is replaced by a fresh 1.0 for the next backward
+    from svbrdf_estimation_amd import _native as native
+
+    def hooked(scale_in_place):
+        w = torch.ones(1, device=dev, requires_grad=True)
+        torch.manual_seed(5)
+        loss = fn(d_in * w, d_tg)
+        loss.register_hook((lambda g: g.mul_(3.0)) if scale_in_place else (lambda g: g * 3.0))
+        before = native.launch_count()
+        loss.backward()
+        torch.cuda.synchronize()
+        return w.grad.clone(), native.launch_count() - before
+    for in_place in (True, False):
+        got, launches = hooked(in_place)
+        assert torch.allclose(got, ws[0] * 3.0, rtol=1e-6, atol=0) and launches == 1, (in_place, got, ws[0], launches)   # the scale launch
+    w = torch.ones(1, device=dev, requires_grad=True)
+    torch.manual_seed(5)
+    loss = fn(d_in * w, d_tg)
+    u = ext.unit_gradient(loss.detach())
+    u.mul_(5.0)                                            # someone scribbles on the cached tensor ...
+    fresh = ext.unit_gradient(loss.detach())
+    assert fresh.item() == 1.0 and fresh.data_ptr() != u.data_ptr()          # ... it is replaced, not trusted
+    torch.Tensor.backward(loss, u)                         # and the scribbled one, handed in explicitly, is an ordinary gradient
+    torch.cuda.synchronize()
+    assert torch.allclose(w.grad, ws[0] * 5.0, rtol=1e-6, atol=0)
+    w2 = torch.ones(1, device=dev, requires_grad=True)
+    torch.manual_seed(5)
+    fn(d_in * w2, d_tg).backward()                         # the next plain backward is exact again
+    torch.cuda.synchronize()
+    assert torch.equal(w2.grad, ws[0])
     # switched off, a leaf's plain backward is the engine's (bench.py's reference leg)
     try:
         losses._UNIT_GRADIENT, saved_fast = False, losses._FAST_BACKWARD

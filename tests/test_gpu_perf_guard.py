@@ -298,15 +298,19 @@ def harness():
 _RESULTS = {}
 
 
+def _flush():
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "perf_guard.json"), "w") as f:
+        json.dump({"device": torch.cuda.get_device_name(0), "results": _RESULTS}, f, indent=1)
+
+
 def _record(name, res, nbytes):
     res = dict(res)
     res["algorithmic_bytes_per_launch"] = nbytes
     res["frac_of_hbm_peak"] = nbytes / (res["us_per_launch"] * 1e-6) / HBM_PEAK
     _RESULTS[name] = res
-    out = os.path.join(ROOT, "gpurun_out")
-    os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "perf_guard.json"), "w") as f:
-        json.dump({"device": torch.cuda.get_device_name(0), "results": _RESULTS}, f, indent=1)
+    _flush()
     print("[perf-guard] %s: %.2f us per launch, %s cycles at %s GHz, %.3f of 8 TB/s" % (
         name, res["us_per_launch"], "%.0f" % res["cycles_per_launch"] if res["cycles_per_launch"] else "-",
         "%.3f" % res["clock_GHz"] if res["clock_GHz"] else "-", res["frac_of_hbm_peak"]))
@@ -386,6 +390,7 @@ def test_fused_photo_synthesis_beats_the_three_pass_form(harness):
     old_us = 1e3 * e0.elapsed_time(e1) / 10
     _RESULTS["k1_noise_clamp_288_photos"]["three_pass_form_us"] = old_us
     _RESULTS["k1_noise_clamp_288_photos"]["speedup_over_three_pass_form"] = old_us / res["us_per_launch"]
+    _flush()
     print("[perf-guard] photos: fused %.1f us, K1 + randn + fma + clamp passes %.1f us" % (res["us_per_launch"], old_us))
     assert old_us >= FUSED_PHOTOS_MIN_SPEEDUP * res["us_per_launch"], (old_us, res)
 
@@ -434,6 +439,8 @@ def test_one_kernel_launch_per_training_step():
         else:
             _RESULTS["launches_per_step_" + name] = {"device_kernels_in_16_steps": None,
                                                      "note": "torch.profiler reported no device events on this build"}
+        _flush()
+        print("[perf-guard] %s: %s" % (name, _RESULTS["launches_per_step_" + name]))
 
 
 if __name__ == "__main__":
