@@ -270,7 +270,7 @@ def copy_peak(dev, gib=1.0):
     ok = bool(torch.equal(src, dst))
     del src, dst
     return {"GBps": 8.0 * n / (ms * 1e-3) / 1e9, "ms_per_launch": ms, "bytes_moved_per_launch": 8.0 * n, "copied_correctly": ok,
-            "kernel": "svbrdf_debug_copy: k_copy_vec4<4, nontemporal>, %.0f MiB read + %.0f MiB written per launch"
+            "kernel": "svbrdf_debug_copy: k_copy_vec4<1, nontemporal>, %.0f MiB read + %.0f MiB written per launch"
                       % (4.0 * n / 2 ** 20, 4.0 * n / 2 ** 20)}
 
 

@@ -735,13 +735,17 @@ __global__ __launch_bounds__(kThreads) void k_render_fwd_inl([[maybe_unused]] co
 
 // K1 with the sensor-noise epilogue (render_inputs, dataset.py:206-219): EPI = 1 clamp, 2 noise + clamp.  The noise levels
 // (one per render) come from a device table, or ride behind the scene rows in the argument block.
+#ifndef SVBRDF_PHOTO_MIN_WAVES
+#define SVBRDF_PHOTO_MIN_WAVES 4    // the Philox state next to four pixels' shading: 137 VGPRs (3 waves/SIMD) left to itself
+#endif
+#define SVBRDF_PHOTO_ATTRS __attribute__((amdgpu_waves_per_eu(SVBRDF_PHOTO_MIN_WAVES, 8)))
 struct PhotoBlock {
     float v[SVBRDF_HOST_SCENES_MAX_ROWS * 9];
     float sigma[SVBRDF_HOST_SCENES_MAX_ROWS];
 };
 
 template <int VEC, int EPI>
-__global__ __launch_bounds__(kThreads) void k_render_inputs(const float *__restrict__ maps,
+__global__ __launch_bounds__(kThreads) SVBRDF_PHOTO_ATTRS void k_render_inputs(const float *__restrict__ maps,
                                                             const float *__restrict__ scenes,
                                                             const float *__restrict__ sigma, PhiloxKey key,
                                                             const float *__restrict__ xrow, float *__restrict__ out,
@@ -751,7 +755,7 @@ __global__ __launch_bounds__(kThreads) void k_render_inputs(const float *__restr
 }
 
 template <int VEC, int EPI>
-__global__ __launch_bounds__(kThreads) void k_render_inputs_inl([[maybe_unused]] const PhotoBlock table, PhiloxKey key,
+__global__ __launch_bounds__(kThreads) SVBRDF_PHOTO_ATTRS void k_render_inputs_inl([[maybe_unused]] const PhotoBlock table, PhiloxKey key,
                                                                 const float *__restrict__ maps,
                                                                 const float *__restrict__ xrow, float *__restrict__ out,
                                                                 int S, int H, int W)
@@ -1565,7 +1569,9 @@ __global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *__restri
 // measurement aid: the HBM copy rate of THIS box ("fraction of both nominal and measured-copy peak").  A plain
 // streaming copy, 16 bytes per lane and access, non-temporal both ways, UNROLL independent loads in flight per lane
 // before the first store; a workgroup owns one contiguous UNROLL x 4 KiB chunk.  Bytes moved = 2 x n x 4.
-// (SVBRDF_COPY_UNROLL / SVBRDF_COPY_NT select the A/B variants of tools/copy_peak.py; shipped: see svbrdf_debug_copy.)
+// SVBRDF_COPY_UNROLL / SVBRDF_COPY_NT select the A/B variants of tools/copy_peak.py.  Shipped: UNROLL = 1, non-temporal --
+// 6.55-6.59 TB/s on 1 and 4 GiB (profiles/r06_copy_peak.txt; unroll 2: 6.1-6.2, 4: 6.3, 8: 4.4-4.5; plain accesses
+// 0.3-0.6 TB/s lower at every unroll; hipMemcpyAsync device-to-device 5.0-5.2; the guide quotes 6.29 for a float4 copy).
 // ------------------------------------------------------------------------------------------
 template <int UNROLL, bool NT>
 __global__ __launch_bounds__(kThreads) void k_copy_vec4(vec4f *__restrict__ dst, const vec4f *__restrict__ src, size_t n4)
@@ -2063,7 +2069,7 @@ int svbrdf_debug_copy(float *dst, const float *src, size_t n, void *stream)
     if (n == 0 || (n & 3) != 0) return fail(SVBRDF_ERR_DIMS, "debug_copy: n must be a positive multiple of 4 floats");
     if (!aligned(dst, 16) || !aligned(src, 16)) return fail(SVBRDF_ERR_ALIGN, "debug_copy: pointers must be 16-byte aligned");
     const int unroll = [] { const char *e = std::getenv("SVBRDF_COPY_UNROLL"); const int v = e ? std::atoi(e) : 0;
-                            return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4; }();
+                            return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 1; }();
     const bool nt = [] { const char *e = std::getenv("SVBRDF_COPY_NT"); return !(e && e[0] == '0'); }();
     const size_t n4 = n / 4, per_block = (size_t)kThreads * unroll, blocks = (n4 + per_block - 1) / per_block;
     if (blocks > 0x7fffffffULL) return fail(SVBRDF_ERR_DIMS, "debug_copy: n too large");

@@ -144,8 +144,11 @@ class _FusedLossTensor(torch.Tensor):
       the autograd engine (19 -> 3 us of host time).
     * otherwise -- a network output, the training case -- the engine runs, but is handed the extension's cached
       device-resident 1.0 as the explicit upstream gradient instead of filling a fresh ones tensor, and the loss's autograd
-      node, recognising that tensor by address, skips its (no-op) scale launch: the step stays ONE kernel launch instead of
-      three (fill, K3, scale).  Same values bit for bit: multiplying by 1.0 is what was skipped.
+      node, recognising that tensor by address and version, skips its (no-op) scale launch: the step stays ONE kernel launch
+      instead of three (fill, K3, scale).  Same values bit for bit: multiplying by 1.0 is what was skipped.  The engine is
+      entered from the extension (``torch::autograd::backward``, the public C++ call) rather than through
+      ``torch.autograd.backward``'s Python front end; a loss someone watches (a hook, ``retain_grad``) or an ``inputs=``
+      call takes the ordinary Python route.
 
     Every other use -- an explicit gradient, ``create_graph=True``, a second ``backward()``, arithmetic on the loss (which
     yields a plain tensor), ``torch.autograd.grad`` -- goes through autograd unchanged."""
@@ -162,11 +165,17 @@ class _FusedLossTensor(torch.Tensor):
             # not when someone watches the loss's gradient (a hook, retain_grad): they get the engine's own fresh ones
             # tensor, theirs to edit; the node then sees an ordinary gradient and applies it
             if _UNIT_GRADIENT and self._backward_hooks is None and not self.retains_grad:
+                if inputs is None and _ENGINE_FROM_NATIVE:
+                    # the same engine run, entered through torch::autograd::backward from the extension (no Python
+                    # argument processing in front of the engine: ~6 us of the ~20 us a step spends on the host)
+                    ext.engine_backward(self, bool(retain_graph))
+                    return None
                 gradient = ext.unit_gradient(inner)
         return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs)
 
 
 _UNIT_GRADIENT = True       # tests switch it off to compare against the engine's own ones tensor
+_ENGINE_FROM_NATIVE = True  # ... and this one to compare against torch.Tensor.backward(loss, unit_gradient)
 
 
 def _check_shapes(input, target):

@@ -1396,17 +1396,23 @@ def test_leaf_backward_shortcut_equals_the_autograd_engine(dev, golden):
     # backward() goes through the engine with the extension's cached unit gradient (no fill kernel, no scale launch) and
     # must give the bits the engine gives with its own ones tensor -- also under retain_graph, and a second time
     ws = []
-    for mode in ("engine", "unit", "unit_retain"):
+    for mode in ("engine", "unit", "unit_python_front_end", "unit_retain"):
         w = torch.ones(1, device=dev, requires_grad=True)
         torch.manual_seed(5)
         loss = fn(d_in * w, d_tg)
         assert isinstance(loss, losses._FusedLossTensor) and loss.__dict__["_svbrdf_src"][1] is None
         if mode == "engine":
             torch.Tensor.backward(loss)
-        elif mode == "unit":
+        elif mode == "unit":                                             # the engine entered from the extension (C++ API)
             loss.backward()
             with pytest.raises(RuntimeError):
                 loss.backward()                                          # freed graph: autograd says so
+        elif mode == "unit_python_front_end":                            # ... and through torch.autograd.backward
+            try:
+                losses._ENGINE_FROM_NATIVE = False
+                loss.backward()
+            finally:
+                losses._ENGINE_FROM_NATIVE = True
         else:
             loss.backward(retain_graph=True)
             first = w.grad.clone()
@@ -1415,7 +1421,21 @@ def test_leaf_backward_shortcut_equals_the_autograd_engine(dev, golden):
             w.grad = first
         torch.cuda.synchronize()
         ws.append(w.grad.clone())
-    assert torch.isfinite(ws[0]).all() and torch.equal(ws[0], ws[1]) and torch.equal(ws[0], ws[2])
+    assert torch.isfinite(ws[0]).all() and all(torch.equal(ws[0], other) for other in ws[1:])
+    # errors raised inside the graph surface as Python exceptions through the native entry too (a Python-defined node that
+    # raises, below the loss)
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise ValueError("boom from a python node")
+    torch.manual_seed(5)
+    loss = fn(Boom.apply(d_in.clone().requires_grad_(True)), d_tg)
+    with pytest.raises((ValueError, RuntimeError), match="boom"):
+        loss.backward()
     # the unit gradient is recognised by ADDRESS: an equal-valued other tensor takes the scaling path, same result
     x = d_in.clone().requires_grad_(True)
     other_one = run(lambda l, x: l.backward(torch.ones((), device=dev)), x=x)
