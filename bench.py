@@ -59,6 +59,17 @@ def parse_args():
     ap.add_argument("--random-scenes", type=int, default=3)
     ap.add_argument("--specular-scenes", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--selftest", action="store_true",
+                    help="first contact with a multi-GPU node (tools/scale_first_contact.md): after the bring-up, every rank "
+                         "all-gathers its GPU's PCI address (N distinct devices expected), times an 8 MB and a 320 MB "
+                         "all-reduce (DDP's payload) and checks the fused loss on its own device against a committed fixture of "
+                         "the reference; prints one JSON line (ranks_seen, distinct_devices, allreduce_GBps, parity) and exits; "
+                         "exit code 3 with a diagnosis on stderr when a check fails or anything hangs past --bringup-timeout")
+    ap.add_argument("--selftest-expect-distinct", action="store_true", help=argparse.SUPPRESS)   # tests: make the self-test fail
+    ap.add_argument("--timed-only", action="store_true",
+                    help="settle, warm-up and the timed region(s) only: none of the untimed follow-up legs (clock probe, the other "
+                         "issue pattern, the other backward modes, copy bandwidth).  For profiler passes: every launch of the "
+                         "fused loss in the process is then a launch of the timed loop")
     ap.add_argument("--no-copy-peak", action="store_true", help="skip the 1 GiB copy-bandwidth leg (2 GiB of device memory)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the K1/K2 stand-alone rates (N=1 only)")
     ap.add_argument("--settle-ms", type=float, default=300.0,
@@ -92,7 +103,9 @@ def parse_args():
                          "median region (at least 9; the 2000-step default form times one region)")
     ap.add_argument("--bringup-timeout", type=float, default=60.0,
                     help="N > 1: seconds the rendezvous + communicator set-up + first all-reduce may take before the rank "
-                         "prints a diagnosis (backend, devices, HSA_ENABLE_IPC_MODE_LEGACY, ...) and exits with code 3")
+                         "prints a diagnosis (backend, devices, HSA_ENABLE_IPC_MODE_LEGACY, ...) and exits with code 3.  The "
+                         "limit covers the rendezvous: raise it for multi-node jobs and cold starts in which ranks page in their "
+                         "images at very different speeds")
     ap.add_argument("--backward", default="engine", choices=("engine", "leaf"),
                     help="how the timed region's loss.backward() runs: 'engine' (default) = through PyTorch's autograd engine, "
                          "what a network output gets -- the training-loop figure; 'leaf' = the engine-free accumulate a plain "
@@ -539,6 +552,27 @@ def main():
 
     from svbrdf_estimation_amd import _native, distributed, losses, renderers
 
+    if args.selftest:
+        # first contact with a multi-GPU node (tools/scale_first_contact.md): distinct devices, all-reduce rates, parity of
+        # the fused loss on every rank's device -- one JSON line, exit code 3 with a diagnosis when anything is off
+        if dist is None:
+            raise SystemExit("--selftest checks a process group: use --gpus N with N > 1, or --gpus 1 --force-dist")
+        res = distributed.first_contact_selftest(dev, nccl, args.share_device and not args.selftest_expect_distinct,
+                                                 os.path.join(ROOT, "tests", "golden", "g3_loss_7_s5.npz"), args.bringup_timeout)
+        places = [None] * dist.get_world_size()
+        dist.all_gather_object(places, placement)
+        if rank == 0:
+            res.update({"metric": "first-contact selftest (no throughput measured)", "selftest": True, "n_gpus": world,
+                        "ranks_seen": ranks_seen, "process_group": "%s, world size %d" % (args.backend, dist.get_world_size()),
+                        "launch": "self-spawned" if os.environ.get("SVBRDF_SELF_SPAWNED") else
+                                  ("external launcher" if world > 1 else "single process"),
+                        "per_rank": {"cpus": [p["cpus"] for p in places], "numa_node": [p["numa_node"] for p in places],
+                                     "pci_crosscheck": [p.get("pci_crosscheck") for p in places]}})
+            print(json.dumps(res), flush=True)
+        barrier()
+        dist.destroy_process_group()
+        return
+
     B, H, S = args.batch, args.size, args.random_scenes + args.specular_scenes
     gen = torch.Generator().manual_seed(distributed.rank_seed(1234, rank))
     inp_h, tgt_h = synthetic_maps(gen, B, H), synthetic_maps(gen, B, H)
@@ -600,6 +634,11 @@ def main():
 
     if not args.engine_threads:
         torch.autograd.set_multithreading_enabled(False)
+    # the two-stream legs visit the same leaf inputs from alternating streams on purpose; torch >= 2.9 warns about the
+    # AccumulateGrad node's stream then (once per process, a paragraph on stderr)
+    quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+    if quiet is not None:
+        quiet(False)
     # `value` is the training-loop figure: loss.backward() through PyTorch's autograd engine (what a network output gets; one
     # kernel launch per step).  The engine-free accumulate a LEAF input resolves to is timed in a follow-up leg
     # (value_leaf_shortcut); --backward leaf makes it the timed region instead (rounds 1-5's `value`).
@@ -694,109 +733,117 @@ def main():
     kernel_ms = sorted(p[0].elapsed_time(p[1]) for p in ev if p is not None)
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
 
-    # ---- untimed follow-up phases (same process, same tensors): the shader clock under this load, and the OTHER way of
-    # issuing the steps (the timed region ran them on one stream -> now alternating on two, and vice versa)
-    state["i"] = -1
-    # The clock the chip holds under this kernel is not one number: it moves between 2.0 and 2.4 GHz within milliseconds
-    # (power management), differs by box, and sags to ~1.75 GHz for ~5 ms when load arrives after an idle period
-    # (tools/clock_timeline.py, profiles/r05_clock_timeline*.txt).  Cycles per launch therefore need clock and duration from
-    # the SAME interval: an event A on the loop's stream opens the interval, the probe stream waits for A and then spins the
-    # one-wave probe for ~3 ms, and an event B closes the interval after as many steps as run in that time.  (Rounds 1-4
-    # paired the timed region's duration with a clock read in a later interval: good to +-8 %.)
-    clock_ghz, clock_note, cycle_leg_ms = None, "not measured", None
-    try:
-        probe_stream = torch.cuda.Stream(dev)
-        probe_out = torch.zeros(2, dtype=torch.int64, device=dev)
-        _native.clock_probe(probe_out, ticks=1, stream=probe_stream)     # first use loads the probe kernel (~6 ms of host time): not inside the interval
-        torch.cuda.synchronize(dev)
-        ms_guess = min(local_elapsed) * 1e3 / args.steps
-        k_leg = int(max(16, min(4096, 3.2 / ms_guess)))        # steps that fill the probe's 3 ms (and a little more)
-        for _ in range(max(64, k_leg, int(12.0 / ms_guess))):   # >= 12 ms of load first: past the onset sag, queue deep when A is recorded
-            step()
-        ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        loop_stream = torch.cuda.current_stream(dev)
-        ev_a.record(loop_stream)
-        probe_stream.wait_event(ev_a)
-        _native.clock_probe(probe_out, ticks=300000, stream=probe_stream)     # 3 ms of the 100 MHz counter, from A on
-        for _ in range(k_leg):
-            step()
-        ev_b.record(loop_stream if not ns else torch.cuda.current_stream(dev))
-        torch.cuda.synchronize(dev)
-        cyc, ticks = (int(v) for v in probe_out.tolist())
-        if ticks > 0:
-            clock_ghz = cyc / ticks * 0.1
-            cycle_leg_ms = ev_a.elapsed_time(ev_b) / k_leg if not ns else None
-            clock_note = ("measured in this run: s_memtime / s_memrealtime of a one-wave probe kernel spinning %.1f ms on its own "
-                          "stream beside %d steps of the bench loop, probe and steps opened by the same event (clock and duration "
-                          "of one interval)" % (ticks * 1e-5, k_leg))
-    except Exception as e:  # pragma: no cover
-        clock_note = "probe failed: %r" % (e,)
-    if ns:
-        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+    # defaults of everything the follow-up legs produce (--timed-only skips them: the profiler passes, whose per-kernel average
+    # should be the timed loop's launches and nothing else)
     main_ns = ns
-    other_ns = 2 if main_ns == 0 else 0
-    other_steps = max(80, min(args.steps, 1024))
-    other_stride = max(1, min(16 if other_ns == 0 else 32, other_steps // 5))
-    ev_other = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % other_stride == 0 else None
-                for i in range(other_steps)]
-    ns = other_ns
-    if ext is not None:
-        for pair in ev_other:
-            if pair is not None:
-                pair[0].record()
-                pair[1].record()
-        torch.cuda.synchronize(dev)
-    ev, raw_ev = ev_other, ([(p[0].cuda_event, p[1].cuda_event) if p is not None else None for p in ev_other]
-                            if ext is not None else [])
-    _native.set_launch_hook(hook)
-    for _ in range(32):                         # let the other issue pattern reach its steady state
-        step()
-    torch.cuda.synchronize(dev)
-    t_other = time.perf_counter()
-    for i in range(other_steps):
-        state["i"] = i
-        step()
-    state["i"] = -1
-    torch.cuda.synchronize(dev)
-    other_ms_per_step = 1e3 * (time.perf_counter() - t_other) / other_steps
-    _native.set_launch_hook(None)
-    if ns:
-        torch.cuda.set_stream(torch.cuda.default_stream(dev))
-    ns = main_ns
-    other_ms = sorted(p[0].elapsed_time(p[1]) for p in ev_other if p is not None)
-    other_ms_avg = sum(other_ms) / len(other_ms)
-    # two more untimed legs, one stream: the OTHER way loss.backward() can run (the timed region took the engine with the unit
-    # gradient: one launch per step) -- the engine-free accumulate a LEAF input gets (losses._FusedLossTensor; torch 2.10 only),
-    # and the engine with its own ones-fill kernel and the node's no-op scale launch (rounds 1-4: three kernels per step).
-    saved_ns, ns = ns, 0
     timed_fast = bool(losses._FAST_BACKWARD)
-    leg_steps = max(600, other_steps)
-
-    def backward_mode_leg(fast, unit):
-        losses._FAST_BACKWARD, losses._UNIT_GRADIENT = fast, unit
-        t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < 20e-3:       # past the clock sag that follows the synchronize above (section 4.4)
-            for _ in range(32):
-                step()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(torch.cuda.current_stream(dev))           # no synchronize in front: the loop keeps running into the timed steps
-        for _ in range(leg_steps):
-            step()
-        e1.record(torch.cuda.current_stream(dev))
-        torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1) / leg_steps
-    leaf_ms_per_step = backward_mode_leg(True, True) if shortcut_available else None
-    engine_ms_per_step = backward_mode_leg(False, True)
-    engine_plain_ms_per_step = backward_mode_leg(False, False)
-    losses._FAST_BACKWARD, losses._UNIT_GRADIENT, ns = timed_fast, True, saved_ns
-
-    # the copy bandwidth of this box, measured in this run (rank 0's GPU; untimed leg)
+    clock_ghz, clock_note, cycle_leg_ms = None, "not measured (--timed-only)", None
+    other_ms_per_step, other_ms, other_steps, leg_steps = None, [], 0, 0
+    leaf_ms_per_step = engine_ms_per_step = engine_plain_ms_per_step = None
     copy = None
-    if rank == 0 and not args.no_copy_peak:
+    if not args.timed_only:
+        # ---- untimed follow-up phases (same process, same tensors): the shader clock under this load, and the OTHER way of
+        # issuing the steps (the timed region ran them on one stream -> now alternating on two, and vice versa)
+        state["i"] = -1
+        # The clock the chip holds under this kernel is not one number: it moves between 2.0 and 2.4 GHz within milliseconds
+        # (power management), differs by box, and sags to ~1.75 GHz for ~5 ms when load arrives after an idle period
+        # (tools/clock_timeline.py, profiles/r05_clock_timeline*.txt).  Cycles per launch therefore need clock and duration from
+        # the SAME interval: an event A on the loop's stream opens the interval, the probe stream waits for A and then spins the
+        # one-wave probe for ~3 ms, and an event B closes the interval after as many steps as run in that time.  (Rounds 1-4
+        # paired the timed region's duration with a clock read in a later interval: good to +-8 %.)
+        clock_ghz, clock_note, cycle_leg_ms = None, "not measured", None
         try:
-            copy = copy_peak(dev)
+            probe_stream = torch.cuda.Stream(dev)
+            probe_out = torch.zeros(2, dtype=torch.int64, device=dev)
+            _native.clock_probe(probe_out, ticks=1, stream=probe_stream)     # first use loads the probe kernel (~6 ms of host time): not inside the interval
+            torch.cuda.synchronize(dev)
+            ms_guess = min(local_elapsed) * 1e3 / args.steps
+            k_leg = int(max(16, min(4096, 3.2 / ms_guess)))        # steps that fill the probe's 3 ms (and a little more)
+            for _ in range(max(64, k_leg, int(12.0 / ms_guess))):   # >= 12 ms of load first: past the onset sag, queue deep when A is recorded
+                step()
+            ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            loop_stream = torch.cuda.current_stream(dev)
+            ev_a.record(loop_stream)
+            probe_stream.wait_event(ev_a)
+            _native.clock_probe(probe_out, ticks=300000, stream=probe_stream)     # 3 ms of the 100 MHz counter, from A on
+            for _ in range(k_leg):
+                step()
+            ev_b.record(loop_stream if not ns else torch.cuda.current_stream(dev))
+            torch.cuda.synchronize(dev)
+            cyc, ticks = (int(v) for v in probe_out.tolist())
+            if ticks > 0:
+                clock_ghz = cyc / ticks * 0.1
+                cycle_leg_ms = ev_a.elapsed_time(ev_b) / k_leg if not ns else None
+                clock_note = ("measured in this run: s_memtime / s_memrealtime of a one-wave probe kernel spinning %.1f ms on its own "
+                              "stream beside %d steps of the bench loop, probe and steps opened by the same event (clock and duration "
+                              "of one interval)" % (ticks * 1e-5, k_leg))
         except Exception as e:  # pragma: no cover
-            copy = {"GBps": None, "error": repr(e)}
+            clock_note = "probe failed: %r" % (e,)
+        if ns:
+            torch.cuda.set_stream(torch.cuda.default_stream(dev))
+        main_ns = ns
+        other_ns = 2 if main_ns == 0 else 0
+        other_steps = max(80, min(args.steps, 1024))
+        other_stride = max(1, min(16 if other_ns == 0 else 32, other_steps // 5))
+        ev_other = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % other_stride == 0 else None
+                    for i in range(other_steps)]
+        ns = other_ns
+        if ext is not None:
+            for pair in ev_other:
+                if pair is not None:
+                    pair[0].record()
+                    pair[1].record()
+            torch.cuda.synchronize(dev)
+        ev, raw_ev = ev_other, ([(p[0].cuda_event, p[1].cuda_event) if p is not None else None for p in ev_other]
+                                if ext is not None else [])
+        _native.set_launch_hook(hook)
+        for _ in range(32):                         # let the other issue pattern reach its steady state
+            step()
+        torch.cuda.synchronize(dev)
+        t_other = time.perf_counter()
+        for i in range(other_steps):
+            state["i"] = i
+            step()
+        state["i"] = -1
+        torch.cuda.synchronize(dev)
+        other_ms_per_step = 1e3 * (time.perf_counter() - t_other) / other_steps
+        _native.set_launch_hook(None)
+        if ns:
+            torch.cuda.set_stream(torch.cuda.default_stream(dev))
+        ns = main_ns
+        other_ms = sorted(p[0].elapsed_time(p[1]) for p in ev_other if p is not None)
+        # two more untimed legs, one stream: the OTHER way loss.backward() can run (the timed region took the engine with the unit
+        # gradient: one launch per step) -- the engine-free accumulate a LEAF input gets (losses._FusedLossTensor; torch 2.10 only),
+        # and the engine with its own ones-fill kernel and the node's no-op scale launch (rounds 1-4: three kernels per step).
+        saved_ns, ns = ns, 0
+        timed_fast = bool(losses._FAST_BACKWARD)
+        leg_steps = max(600, other_steps)
+
+        def backward_mode_leg(fast, unit):
+            losses._FAST_BACKWARD, losses._UNIT_GRADIENT = fast, unit
+            t_settle = time.perf_counter()
+            while time.perf_counter() - t_settle < 20e-3:       # past the clock sag that follows the synchronize above (section 4.4)
+                for _ in range(32):
+                    step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))           # no synchronize in front: the loop keeps running into the timed steps
+            for _ in range(leg_steps):
+                step()
+            e1.record(torch.cuda.current_stream(dev))
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1) / leg_steps
+        leaf_ms_per_step = backward_mode_leg(True, True) if shortcut_available else None
+        engine_ms_per_step = backward_mode_leg(False, True)
+        engine_plain_ms_per_step = backward_mode_leg(False, False)
+        losses._FAST_BACKWARD, losses._UNIT_GRADIENT, ns = timed_fast, True, saved_ns
+
+        # the copy bandwidth of this box, measured in this run (rank 0's GPU; untimed leg)
+        copy = None
+        if rank == 0 and not args.no_copy_peak:
+            try:
+                copy = copy_peak(dev)
+            except Exception as e:  # pragma: no cover
+                copy = {"GBps": None, "error": repr(e)}
 
     if rank == 0:
         patches = world * B * args.steps
@@ -812,8 +859,13 @@ def main():
             one = {"ms_per_step": other_ms_per_step, "kernel_ms": other_ms, "steps": other_steps, "leg": follow_up}
             two = {"ms_per_step": ms_per_step, "kernel_ms": kernel_ms, "steps": args.steps, "streams": main_ns,
                    "leg": "the timed region"}
-        one_kernel_avg = sum(one["kernel_ms"]) / len(one["kernel_ms"])
-        two_kernel_avg = sum(two["kernel_ms"]) / len(two["kernel_ms"])
+
+        def rate(ms, n=1):          # patches/s of n GPUs at `ms` per step; None when the leg did not run (--timed-only)
+            return n * B / (ms * 1e-3) if ms else None
+
+        def avg(v):
+            return sum(v) / len(v) if v else None
+        one_kernel_avg, two_kernel_avg = avg(one["kernel_ms"]), avg(two["kernel_ms"])
         # ONE clock: the roofline is priced with the interval `value` is priced with (wall time of the median region, MAX
         # over ranks, / steps): frac x peak x ms_per_step / bytes == 1.  What rounds 1-5 priced it with -- the HIP event
         # pair around the region on the launch stream / launches, 2-3 % shorter (no barrier, no synchronize, no host tail) --
@@ -821,7 +873,7 @@ def main():
         achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9
         events_ms = region_ms_per_launch if n_streams == 1 else None
         achieved_events = alg_bytes / (events_ms * 1e-3) / 1e9 if events_ms else None
-        achieved_two = alg_bytes / (two["ms_per_step"] * 1e-3) / 1e9
+        achieved_two = alg_bytes / (two["ms_per_step"] * 1e-3) / 1e9 if two["ms_per_step"] else None
         copy_gbps = copy.get("GBps") if copy else None
         valu_issue = None
         traffic, traffic_source, tj = replayed_counters(_native.library_path(), B, H, S)
@@ -847,8 +899,8 @@ def main():
         timed_is = ("loss.backward() through PyTorch's autograd engine (what a network output gets: the training-loop figure; one "
                     "kernel launch per step)" if not timed_fast else
                     "the engine-free accumulate a plain loss.backward() on a LEAF input resolves to (--backward leaf)")
-        value_leaf = world * B / (leaf_ms_per_step * 1e-3) if leaf_ms_per_step else None
-        value_engine = patches / elapsed if not timed_fast else world * B / (engine_ms_per_step * 1e-3)
+        value_leaf = rate(leaf_ms_per_step, world)
+        value_engine = patches / elapsed if not timed_fast else rate(engine_ms_per_step, world)
         out = {
             "metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)",
             "value": patches / elapsed, "unit": "patches/s", "n_gpus": world,
@@ -857,10 +909,11 @@ def main():
             # the same figure under its round-5 name (then a follow-up leg; since round 6 it IS the timed region)
             "value_through_autograd_engine": value_engine,
             "value_leaf_shortcut": value_leaf if not timed_fast else patches / elapsed,
-            "value_through_autograd_engine_with_fill_and_scale_launches": world * B / (engine_plain_ms_per_step * 1e-3),
+            "value_through_autograd_engine_with_fill_and_scale_launches": rate(engine_plain_ms_per_step, world),
             "valu_issue_frac": valu_issue["frac"] if valu_issue else None,      # what bounds K3 (also in roofline, with its inputs)
-            "value_single_stream": world * B / (one["ms_per_step"] * 1e-3),
-            "value_two_streams_overlapped": world * B / (two["ms_per_step"] * 1e-3),
+            "value_single_stream": rate(one["ms_per_step"], world),
+            "value_two_streams_overlapped": rate(two["ms_per_step"], world),
+            "follow_up_legs": "skipped (--timed-only)" if args.timed_only else "run",
             "copy_peak_GBps_measured": copy_gbps,
             "timed_regions": {"count": n_regions, "steps_each": args.steps, "median_index": median_region,
                               "ms_per_step": [1e3 * e / args.steps for e in job_elapsed],
@@ -938,23 +991,24 @@ def main():
                          "valu_frac_of_fp32_peak": (FLOP_PER_PIXEL_SCENE * H * H * S * B / (ms_per_step * 1e-3))
                                                    / (FP32_VALU_PEAK_TFLOPS * 1e12),
                          "valu_issue": valu_issue},
-            "single_stream": {"patches_per_s": B / (one["ms_per_step"] * 1e-3), "ms_per_step": one["ms_per_step"],
-                              "kernel_ms_avg": one_kernel_avg, "kernel_ms_median": one["kernel_ms"][len(one["kernel_ms"]) // 2],
+            "single_stream": {"patches_per_s": rate(one["ms_per_step"]), "ms_per_step": one["ms_per_step"],
+                              "kernel_ms_avg": one_kernel_avg,
+                              "kernel_ms_median": one["kernel_ms"][len(one["kernel_ms"]) // 2] if one["kernel_ms"] else None,
                               "kernel_launches_timed": len(one["kernel_ms"]), "steps": one["steps"], "leg": one["leg"]},
-            "two_streams_overlapped": {"patches_per_s": B / (two["ms_per_step"] * 1e-3), "ms_per_step": two["ms_per_step"],
+            "two_streams_overlapped": {"patches_per_s": rate(two["ms_per_step"]), "ms_per_step": two["ms_per_step"],
                                        "streams": two["streams"], "kernel_ms_avg_while_overlapped": two_kernel_avg,
                                        "steps": two["steps"], "leg": two["leg"],
-                                       "roofline_frac_of_time_share": achieved_two / HBM_PEAK_GBPS,
+                                       "roofline_frac_of_time_share": achieved_two / HBM_PEAK_GBPS if achieved_two else None,
                                        "note": "per GPU: step k (launch + backward) on stream k mod 2; the steps are independent "
                                                "batches, so one step's kernel fills the ramp and tail of the other's.  A "
                                                "bench-loop property: not what one training loop gets"},
             "backward_modes": {
                 "timed_region": "engine" if not timed_fast else "leaf shortcut",
-                "engine_one_launch_per_step": {"patches_per_s": B / (engine_ms_per_step * 1e-3), "ms_per_step": engine_ms_per_step},
-                "engine_with_fill_and_scale_launches": {"patches_per_s": B / (engine_plain_ms_per_step * 1e-3),
+                "engine_one_launch_per_step": {"patches_per_s": rate(engine_ms_per_step), "ms_per_step": engine_ms_per_step},
+                "engine_with_fill_and_scale_launches": {"patches_per_s": rate(engine_plain_ms_per_step),
                                                         "ms_per_step": engine_plain_ms_per_step},
-                "leaf_shortcut": {"patches_per_s": B / (leaf_ms_per_step * 1e-3), "ms_per_step": leaf_ms_per_step}
-                                 if leaf_ms_per_step else "not available on this torch version",
+                "leaf_shortcut": {"patches_per_s": rate(leaf_ms_per_step), "ms_per_step": leaf_ms_per_step}
+                                 if leaf_ms_per_step else ("not run" if args.timed_only else "not available on this torch version"),
                 "steps_each": leg_steps,
                 "note": "per GPU, untimed follow-up legs on one stream, HIP events around each.  engine_one_launch_per_step: the "
                         "engine is handed the extension's cached device-resident 1.0 and the node, recognising it by address and "

@@ -106,6 +106,52 @@ def test_bench_eight_self_spawned_ranks_as_the_scaling_run_starts_it():
     print("bench.py, eight ranks on one device: %.0f patches/s aggregate; slices %s" % (line["value"], pr["cpus"]))
 
 
+def _check_selftest_line(line, world, transport):
+    assert line["selftest"] is True and line["ok"] is True and line["ranks_seen"] == world == line["n_gpus"]
+    assert line["distinct_devices"] == line["distinct_devices_expected"] and len(line["pci_bus_ids"]) == world
+    assert line["transport"].startswith(transport) and line["allreduce_sums_correct"] is True
+    for size in ("8MB", "320MB"):
+        assert len(line["allreduce_GBps"][size]) == world and all(v > 0 for v in line["allreduce_GBps"][size])
+    assert len(line["parity"]) == world
+    for p in line["parity"]:
+        assert p["ok"] and p["loss_rel_err"] <= 2e-6 and p["grad_outside_tolerance"] <= 8, p
+
+
+def test_selftest_first_contact_over_rccl_world_of_one():
+    """tools/scale_first_contact.md step 1 on the one GPU a box has: `bench.py --gpus 1 --force-dist --selftest` -- RCCL
+    bring-up, PCI all-gather, the 8 MB and 320 MB all-reduces on device tensors, the fused loss against the committed
+    reference fixture; one JSON line with ranks_seen / distinct_devices / allreduce_GBps"""
+    line, _ = _run("bench.py", "--gpus", 1, "--force-dist", "--selftest")
+    _check_selftest_line(line, 1, "RCCL")
+    assert line["distinct_devices"] == 1 and line["process_group"].startswith("nccl")
+    print("selftest over RCCL, world 1: device %s, 320 MB all-reduce call %.2f ms, parity %s" % (
+        line["pci_bus_ids"], 1e3 * line["allreduce_seconds"]["320MB"][0], line["parity"][0]))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "selftest_rccl_world1.json"), "w") as f:
+        json.dump(line, f, indent=1)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_selftest_first_contact_self_spawned_ranks_share_the_device(world):
+    """the same self-test as the driver's node would start it (`python bench.py --gpus N --selftest`, self-spawned), N ranks
+    on this box's one GPU over gloo: every rank gathers, reduces and checks parity on the device"""
+    line, _ = _run("bench.py", "--gpus", world, "--backend", "gloo", "--share-device", "--selftest", timeout=1500)
+    _check_selftest_line(line, world, "gloo")
+    assert line["launch"] == "self-spawned" and line["distinct_devices"] == 1 and len(set(line["pci_bus_ids"])) == 1
+    print("selftest, %d ranks on one device (gloo): 320 MB all-reduce %s GB/s" % (
+        world, ["%.1f" % v for v in line["allreduce_GBps"]["320MB"]]))
+
+
+def test_selftest_that_finds_ranks_sharing_a_gpu_exits_with_code_3():
+    """the failure the self-test exists for: N ranks, fewer than N distinct GPUs (here: two ranks told to expect their own
+    device each while sharing cuda:0) -> exit code 3 and the reason on stderr, no hang, no JSON verdict of success"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
+                        "--selftest", "--selftest-expect-distinct"], env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert "[selftest] FAILED" in r.stderr and "distinct GPUs" in r.stderr, r.stderr[-2000:]
+    assert not any(l.strip().startswith("{") and '"ok": true' in l for l in r.stdout.splitlines())
+
+
 def test_train_rccl_ddp_world_of_one():
     """train.py's N > 1 branches over RCCL at world size 1: process group with device_id, DistributedDataParallel
     around the U-Net (bucketed all-reduce of its 320 MB of gradients through RCCL), fused MixedLoss, barriers, the

@@ -23,7 +23,7 @@ if [ -z "${SKIP_SUITE:-}" ]; then
   python3 train.py --gpus 2 --backend gloo --share-device --steps 10 --warmup 3 --batch 8 > $OUT/${TAG}_train_2ranks_share_device.json 2>/dev/null
 fi
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-secondary"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-secondary --timed-only"
 # kernel-trace + stats (no counters in these passes): the default command (every step on one stream: the duration of a
 # launch on its own) and the same with the steps alternating on two streams (launches overlap, so the per-launch duration
 # exceeds a launch's share of the GPU: what bench.py reports as two_streams_overlapped)

@@ -44,7 +44,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         print(json.dumps(measure(float(sys.argv[2]))), flush=True)
         sys.exit(0)
-    grid = [(4, 1, 1.0)] if "--one" in sys.argv else [(u, nt, g) for g in (1.0, 4.0) for nt in (1, 0) for u in (1, 2, 4, 8)]
+    grid = [(1, 1, 1.0)] if "--one" in sys.argv else [(u, nt, g) for g in (1.0, 4.0) for nt in (1, 0) for u in (1, 2, 4, 8)]
     for unroll, nt, gib in grid:
         env = dict(os.environ, SVBRDF_COPY_UNROLL=str(unroll), SVBRDF_COPY_NT=str(nt))
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(gib)], env=env, capture_output=True, text=True)

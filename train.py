@@ -115,7 +115,8 @@ def parse_args(argv=None):
                          "loss to this file")
     ap.add_argument("--bringup-timeout", type=float, default=60.0,
                     help="multi-rank: seconds the rendezvous + communicator set-up + first all-reduce may take before the "
-                         "rank prints a diagnosis and exits with code 3")
+                         "rank prints a diagnosis and exits with code 3 (the limit covers the rendezvous: raise it for multi-node "
+                         "jobs and slow cold starts)")
     ap.add_argument("--no-ddp-probe", action="store_true",
                     help="skip the eight untimed steps after the timed region that time a whole step's forward + backward "
                          "with DDP's all-reduce and under model.no_sync() (multi-rank GPU runs; CPU runs with --ddp-probe)")
