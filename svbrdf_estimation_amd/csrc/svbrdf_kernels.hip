@@ -1382,6 +1382,10 @@ __device__ __forceinline__ void rendering_loss_body(const float *__restrict__ in
         if (WITH_GRAD && !HEAD) {       // timing build: entry / exit stamps of the wave beside the loop's (loss_scene_loop)
             acc.d[0] = (float)(t_entry & 0xffffff);
             acc.d[1] = (float)(wall_clock64() & 0xffffff);
+            // where the wave ran (tools/k3_placement.py: is the first resident round placed breadth-first over the CUs, as the
+            // load stagger above assumes?): HW_ID (hwreg 4: CU_ID [11:8], SH_ID [12], SE_ID [15:13]) and XCC_ID (hwreg 20, [3:0])
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+            acc.d[2] = (float)(((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u));
         }
 #endif
         if (WITH_GRAD) store_pixel_grad<HEAD>(head, acc, grad_input, b, plane, pix);

@@ -6,6 +6,37 @@ from . import data, models  # noqa: F401
 
 
 _working_copy = {}      # in-tree cache directory -> the writable copy MIOpen was pointed at
+_locks = []             # open .lock files of the copies this process holds (flock: released when the process ends)
+_MAX_COPIES = 64
+
+
+def _not_private(path):
+    """why `path` may not be trusted as a private directory of this user (None: it may): it must be a real directory (no
+    symlink), owned by this uid, without any permission for group or others"""
+    import os
+    import stat
+    st = os.lstat(path)
+    if not stat.S_ISDIR(st.st_mode):
+        return "is not a directory (a symlink or file sits there)"
+    if st.st_uid != os.getuid():
+        return "is owned by uid %d, not by this user (%d)" % (st.st_uid, os.getuid())
+    if st.st_mode & 0o077:
+        return "is open to group/others (mode %o; need 0700)" % (st.st_mode & 0o777)
+    return None
+
+
+def _lock_copy(dst):
+    """exclusive, non-blocking flock on <dst>/.lock, held until this process exits -> True if this process now owns the copy"""
+    import fcntl
+    import os
+    fd = os.open(os.path.join(dst, ".lock"), os.O_RDWR | os.O_CREAT, 0o600)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX | fcntl.LOCK_NB)
+    except OSError:
+        os.close(fd)
+        return False
+    _locks.append(fd)
+    return True
 
 
 def _manifest_mismatches(cache_dir):
@@ -42,9 +73,15 @@ def use_in_tree_miopen_cache(source=None, home=None):
 
       * the tracked files are checked against MANIFEST.json; a cache whose files no longer match is REFUSED (warning,
         MIOpen's own default cache is used): nobody runs an unreviewable binary blob that differs from the recorded one;
-      * they are copied once to a writable per-user directory, ``<home>/miopen-<manifest sha256[:16]>/r<LOCAL_RANK>``
-        (home: $SVBRDF_MIOPEN_CACHE_HOME, else ~/.cache/svbrdf_amd, else the system temp directory; one copy per local
-        rank, so ranks never share a database file), and MIOPEN_CUSTOM_CACHE_DIR / MIOPEN_USER_DB_PATH point there;
+      * they are copied to a writable PRIVATE directory, ``<home>/miopen-<manifest sha256[:16]>/r<LOCAL_RANK>[.<slot>]``
+        (home: $SVBRDF_MIOPEN_CACHE_HOME, else ~/.cache/svbrdf_amd, else ``<tmp>/svbrdf_amd-<uid>``), and
+        MIOPEN_CUSTOM_CACHE_DIR / MIOPEN_USER_DB_PATH point there.  Every directory on the way is created with mode 0700
+        and must be owned by this user and closed to group and others -- a directory found there that is not (another
+        local user can pre-create a predictable path under /tmp and fill it with kernel binaries of their own) is refused,
+        never adopted.  A copy belongs to ONE process tree at a time: the process holds an exclusive ``flock`` on its
+        ``.lock`` for as long as it lives, and one that finds ``r0`` taken (another job of the same user on this node,
+        a second test session) takes ``r0.1``, ``r0.2``, ...: no two jobs write one sqlite file, and the number of copies is
+        bounded by the number of jobs that ever ran at once;
       * a user who has set either variable keeps their own cache.
 
     Purely a compile/search cache: the kernels are the ones a fresh box builds for itself.  Must run before the first
@@ -61,7 +98,7 @@ def use_in_tree_miopen_cache(source=None, home=None):
         # a parent process (the test suite, a self-spawning launcher) already did this: its copy serves this process too
         # when it is the same local rank's; another rank takes a copy of its own next to it
         inherited = os.path.dirname(os.environ["MIOPEN_CUSTOM_CACHE_DIR"])
-        if os.path.basename(inherited) == rank_dir:
+        if os.path.basename(inherited).split(".")[0] == rank_dir:
             _working_copy.setdefault(here, inherited)
             return here
         home = home or os.path.dirname(os.path.dirname(inherited))
@@ -74,22 +111,37 @@ def use_in_tree_miopen_cache(source=None, home=None):
         return None
     bases = [home or os.environ.get("SVBRDF_MIOPEN_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache", "svbrdf_amd"),
              os.path.join(tempfile.gettempdir(), "svbrdf_amd-%d" % os.getuid())]
+    refused = []
     for base in bases:
-        dst = os.path.join(base, "miopen-%s" % sha[:16], rank_dir)
+        root = os.path.join(base, "miopen-%s" % sha[:16])
         try:
-            if not os.path.isdir(os.path.join(dst, "cache")):
-                os.makedirs(os.path.dirname(dst), exist_ok=True)
-                tmp = tempfile.mkdtemp(prefix=rank_dir + ".tmp", dir=os.path.dirname(dst))
-                for sub in ("cache", "db"):
-                    if os.path.isdir(os.path.join(here, sub)):
-                        shutil.copytree(os.path.join(here, sub), os.path.join(tmp, sub))
-                try:
-                    os.rename(tmp, dst)             # atomic: a concurrent starter of the same rank directory wins or loses whole
-                except OSError:
-                    shutil.rmtree(tmp, ignore_errors=True)
-            if not os.access(os.path.join(dst, "cache"), os.W_OK):
-                continue
-        except OSError:
+            for d in (base, root):
+                os.makedirs(d, mode=0o700, exist_ok=True)
+                why = _not_private(d)
+                if why:
+                    raise PermissionError("%s %s" % (d, why))
+            for slot in range(_MAX_COPIES):
+                dst = os.path.join(root, rank_dir if slot == 0 else "%s.%d" % (rank_dir, slot))
+                if not os.path.isdir(os.path.join(dst, "cache")):
+                    tmp = tempfile.mkdtemp(prefix=os.path.basename(dst) + ".tmp", dir=root)      # mkdtemp: mode 0700
+                    for sub in ("cache", "db"):
+                        if os.path.isdir(os.path.join(here, sub)):
+                            shutil.copytree(os.path.join(here, sub), os.path.join(tmp, sub))
+                    try:
+                        os.rename(tmp, dst)         # atomic: a concurrent starter of the same directory wins or loses whole
+                    except OSError:
+                        shutil.rmtree(tmp, ignore_errors=True)
+                why = _not_private(dst)
+                if why:
+                    raise PermissionError("%s %s" % (dst, why))
+                if not os.access(os.path.join(dst, "cache"), os.W_OK):
+                    raise PermissionError("%s is not writable" % os.path.join(dst, "cache"))
+                if _lock_copy(dst):
+                    break                           # ours for the life of this process
+            else:
+                raise OSError("all %d copies under %s are in use" % (_MAX_COPIES, root))
+        except OSError as e:
+            refused.append(str(e))
             continue
         os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(dst, "cache")
         if os.path.isdir(os.path.join(dst, "db")):
@@ -97,6 +149,7 @@ def use_in_tree_miopen_cache(source=None, home=None):
         os.environ["SVBRDF_MIOPEN_CACHE_SOURCE"] = here
         _working_copy[here] = dst
         return here
+    bases = ["%s" % r for r in refused] or bases
     warnings.warn("no writable directory for a copy of the in-tree MIOpen cache (tried %s): not used" % ", ".join(bases))
     return None
 

@@ -220,6 +220,39 @@ def test_bring_up_error_can_be_an_exception_for_library_callers():
     assert r.returncode == 3 and "[bring-up] rank 0 of 1" in r.stderr and "RAISED" not in r.stdout, (r.returncode, r.stderr[-800:])
 
 
+def test_bring_up_error_after_a_successful_init_leaves_no_group_behind_and_can_be_retried():
+    """exit_on_failure=False when the group DID come up but the first collective counts the wrong number of ranks: the
+    default group is destroyed again before the error is raised, so the caller can retry (a second init_process_group
+    would otherwise fail with "initialised twice" and the half-checked communicator would stay alive); the watchdog leaves
+    faulthandler's process-wide timer to whoever armed it."""
+    import subprocess
+    code = ("import os, sys, faulthandler; sys.path.insert(0, %r)\n"
+            "from svbrdf_estimation_amd import launch\n"
+            "os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(launch.free_port()))\n"
+            "import torch.distributed as dist\n"
+            "from svbrdf_estimation_amd import distributed as D\n"
+            "faulthandler.dump_traceback_later(3.0, exit=True)          # the application's own hang dump: must survive\n"
+            "real = dist.all_reduce\n"
+            "def doubled(t, op=None, **kw):\n"
+            "    real(t, op=op, **kw); t.mul_(2)                        # the collective 'sees' two ranks in a world of one\n"
+            "dist.all_reduce = doubled\n"
+            "try:\n"
+            "    D.init_process_group_checked('gloo', None, 30.0, exit_on_failure=False)\n"
+            "    raise SystemExit('no error raised')\n"
+            "except D.ProcessGroupBringupError as e:\n"
+            "    assert 'summed 2 ones over a group of 1' in str(e), e\n"
+            "assert not dist.is_initialized()\n"
+            "dist.all_reduce = real\n"
+            "assert D.init_process_group_checked('gloo', None, 30.0, exit_on_failure=False) == 1   # the retry\n"
+            "dist.destroy_process_group()\n"
+            "print('RETRIED', flush=True)\n"
+            "import time; time.sleep(5)                                  # the timer armed above was not cancelled by the watchdog\n"
+            "print('TIMER-LOST')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=_clean_env(), capture_output=True, text=True, timeout=120)
+    assert "RETRIED" in r.stdout and "TIMER-LOST" not in r.stdout and r.returncode == 1, (r.returncode, r.stdout, r.stderr[-1500:])
+    assert "Timeout (0:00:03)!" in r.stderr
+
+
 def test_bench_refuses_a_world_that_is_not_gpus():
     """a launcher environment whose WORLD_SIZE contradicts --gpus must be an error, not a silent 1-rank run"""
     import subprocess

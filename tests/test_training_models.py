@@ -141,9 +141,34 @@ def test_miopen_cache_is_used_through_a_writable_copy_and_refused_when_tampered(
     monkeypatch.setenv("LOCAL_RANK", "3")
     assert training.use_in_tree_miopen_cache() == here
     assert os.environ["MIOPEN_CUSTOM_CACHE_DIR"] == os.path.join(os.path.dirname(os.path.dirname(cache_dir)), "r3", "cache")
-    # the user's own setting wins
+    # another job of the same user on this node (nothing inherited, LOCAL_RANK unset again): r0 is held -- flock -- by the
+    # first, so it gets a copy of its own next to it instead of writing the same sqlite file
     for var in ("MIOPEN_CUSTOM_CACHE_DIR", "MIOPEN_USER_DB_PATH", "SVBRDF_MIOPEN_CACHE_SOURCE", "LOCAL_RANK"):
         monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(training, "_working_copy", {})
+    assert training.use_in_tree_miopen_cache(home=home) == here
+    assert os.environ["MIOPEN_CUSTOM_CACHE_DIR"] == os.path.join(os.path.dirname(os.path.dirname(cache_dir)), "r0.1", "cache")
+    # every directory on the way is private: created 0700, and a directory somebody else could have prepared (here: one
+    # open to group/others; a foreign owner cannot be staged without root) is refused, not adopted
+    import stat
+    for d in (home, os.path.dirname(os.path.dirname(cache_dir)), os.path.dirname(cache_dir)):
+        assert stat.S_IMODE(os.lstat(d).st_mode) == 0o700, d
+    for var in ("MIOPEN_CUSTOM_CACHE_DIR", "MIOPEN_USER_DB_PATH", "SVBRDF_MIOPEN_CACHE_SOURCE"):
+        monkeypatch.delenv(var, raising=False)
+    planted = str(tmp_path / "planted")
+    os.makedirs(planted, mode=0o755)
+    os.chmod(planted, 0o755)
+    (tmp_path / "a-file").write_text("not a directory")
+    monkeypatch.setattr("tempfile.gettempdir", lambda: str(tmp_path / "a-file"))      # no second base to fall back on
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert training.use_in_tree_miopen_cache(home=planted) is None
+    assert w and "open to group/others" in str(w[0].message) and "MIOPEN_CUSTOM_CACHE_DIR" not in os.environ
+    assert os.listdir(planted) == []
+    monkeypatch.undo()
+    for var in ("MIOPEN_CUSTOM_CACHE_DIR", "MIOPEN_USER_DB_PATH", "SVBRDF_MIOPEN_CACHE_SOURCE", "LOCAL_RANK"):
+        monkeypatch.delenv(var, raising=False)
+    # the user's own setting wins
     monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")
     assert training.use_in_tree_miopen_cache(home=home) is None and "MIOPEN_CUSTOM_CACHE_DIR" not in os.environ
     monkeypatch.delenv("MIOPEN_USER_DB_PATH")
