@@ -39,7 +39,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTI
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_SMEM -d $OUT/${TAG}_pmc_sq2 --output-format csv -- $BENCH --steps 20 --warmup 5 > $OUT/${TAG}_pmc_sq2.log 2>&1
 # the other kernels and K3's other variants, one process per case (tools/kernel_cases.py): kernel-trace stats, then
 # FETCH_SIZE and WRITE_SIZE in their own passes -- the HBM-bound K1 / K2 / K4 and the loss variants the headline does not run
-for c in ${CASES:-k1 k2 k4 k3_mixed k3_head k3_head_l1 k3_untied k3_config4 k3_config5}; do
+for c in ${CASES:-k1 k2 k4 photos copy synthesis k3_mixed k3_head k3_head_l1 k3_untied k3_config4 k3_config5}; do
   timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_case_${c}_stats --output-format csv -- python3 $R/tools/kernel_cases.py $c 60 > $OUT/${TAG}_case_${c}.log 2>&1
   timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_case_${c}_fetch --output-format csv -- python3 $R/tools/kernel_cases.py $c 12 >> $OUT/${TAG}_case_${c}.log 2>&1
   timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_case_${c}_write --output-format csv -- python3 $R/tools/kernel_cases.py $c 12 >> $OUT/${TAG}_case_${c}.log 2>&1
@@ -57,5 +57,14 @@ timeout 400 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 # back-to-back launches through the C ABI, cycles at the clock under load (the GPU suite's speed guard, as a script)
 PERF_GUARD_REPEATS=2 timeout 200 python3 tests/test_gpu_perf_guard.py > $OUT/${TAG}_perf_guard.txt 2>&1 && cp $OUT/perf_guard.json $OUT/${TAG}_perf_guard.json
 timeout 60 python3 tools/clock_timeline.py > $OUT/${TAG}_clock_timeline.txt 2>&1
+# the copy kernel's A/B grid (the measured-copy peak bench.py prices the HBM-bound kernels against) and the placement
+# check of K3's load stagger (timing builds of tools/build_variant.sh, when they travelled with the snapshot)
+timeout 300 python3 tools/copy_peak.py > $OUT/${TAG}_copy_peak.txt 2>&1
+for v in tim tim0; do
+  [ -f tools/_build/libsvbrdf_$v.so ] && SVBRDF_HIP_LIB=tools/_build/libsvbrdf_$v.so timeout 120 python3 tools/k3_placement.py > $OUT/${TAG}_k3_placement_$v.txt 2>&1
+done
+# first contact self-test, as far as one GPU goes: RCCL world 1, and eight self-spawned ranks sharing the device over gloo
+timeout 200 python3 bench.py --gpus 1 --force-dist --selftest > $OUT/${TAG}_selftest_rccl_world1.json 2> $OUT/${TAG}_selftest_rccl_world1.err
+timeout 400 python3 bench.py --gpus 8 --backend gloo --share-device --selftest > $OUT/${TAG}_selftest_8ranks_share_device.json 2> $OUT/${TAG}_selftest_8ranks_share_device.err
 [ -x tools/_build/valu_rate ] && timeout 100 tools/_build/valu_rate > $OUT/${TAG}_valu_rate.txt 2>&1
 tail -c 600 $OUT/${TAG}_bench.json

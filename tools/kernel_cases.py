@@ -4,7 +4,9 @@ rocprofv3 wraps for the per-kernel evidence under profiles/ (tools/collect_profi
 separate passes, the FETCH_SIZE / WRITE_SIZE counters.  Not product code.
 
     python3 tools/kernel_cases.py <case> [launches]
-cases:  k1 k2 (288 renders, one per map)   k4 (64 samples)   k3_render k3_mixed k3_head k3_head_l1 k3_untied (config 2:
+cases:  k1 k2 (288 renders, one per map)   photos (K1 + sensor noise + clamp: 288 photos, one per map)   copy (1 GiB -> 1 GiB)
+        synthesis (synthesis.render_inputs(B = 8, one photo each), a call after the other: ONE kernel per call)
+        k4 (64 samples)   k3_render k3_mixed k3_head k3_head_l1 k3_untied (config 2:
         B=8, 256x256, 9 scenes)   k3_config4 (B=16, mixed)   k3_config5 (B=8, 512x512, 11+21 scenes)
 Prints one JSON line: case, kernel name pattern, algorithmic bytes per launch, launches.
 """
@@ -36,6 +38,30 @@ def main():
             call, nbytes, kern = (lambda: _native.render_fwd(maps, table)), 60.0 * H * H * B, "k_render_fwd"
         else:
             call, nbytes, kern = (lambda: _native.render_bwd(maps, table, cot)), 108.0 * H * H * B, "k_render_bwd"
+    elif case == "photos":
+        from svbrdf_estimation_amd import synthesis
+        B = 288
+        maps = synthetic_maps(gen, B, H).to(dev)
+        torch.manual_seed(7)
+        table = torch.stack([synthesis.input_scene_table(1, True) for _ in range(B)]).to(dev)
+        levels = synthesis.noise_levels(B).view(B, 1).to(dev)
+        state = {"k": 0}
+
+        def call():
+            state["k"] += 1
+            _native.render_inputs(maps, table, levels, 99, 4 * state["k"])
+        nbytes, kern = 60.0 * H * H * B, "k_render_inputs"
+    elif case == "copy":
+        nf = (1 << 30) // 4
+        src = torch.empty(nf, device=dev).uniform_(-1.0, 1.0)
+        dst = torch.empty_like(src)
+        call, nbytes, kern = (lambda: _native.debug_copy(dst, src)), 8.0 * nf, "k_copy_vec4"
+    elif case == "synthesis":
+        from svbrdf_estimation_amd import synthesis
+        B = 8
+        maps = synthetic_maps(gen, B, H).to(dev)
+        torch.manual_seed(7)
+        call, nbytes, kern = (lambda: synthesis.render_inputs(maps, 1)), 60.0 * H * H * B, "k_render_inputs"
     elif case == "k4":
         B = 64
         sets = [(synthetic_maps(gen, B, H).to(dev), synthetic_maps(gen, B, H).to(dev)) for _ in range(2)]

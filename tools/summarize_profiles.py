@@ -145,19 +145,24 @@ for log in sorted(glob.glob(os.path.join(G, "%s_case_*.log" % tag))):
         row["hbm_bytes_per_launch"] = row["read_bytes_x2_corrected"] + row["write_bytes"]
         row["traffic_over_algorithmic"] = row["hbm_bytes_per_launch"] / alg
     cases[c] = row
+syn = one("%s_case_synthesis_stats/*/*_kernel_stats.csv" % tag)
+if syn:     # every kernel of a process that only calls synthesis.render_inputs: one k_render_inputs_inl launch per call, nothing else
+    shutil.copy(syn, os.path.join(P, "%s_synthesis_kernel_stats.csv" % tag))
 if cases:
     json.dump({"note": "rocprofv3 --kernel-trace --stats average duration per kernel and, from separate --pmc passes, FETCH_SIZE / "
                        "WRITE_SIZE per launch (KiB; reads doubled per the gfx950 note of MI355X_MICROARCH.md: exact for 16 B per "
                        "lane streaming reads, validated on K3's dword reads in round 2; the 8 B per lane reads of K2 are "
                        "uncalibrated).  Working sets beyond the 256 MiB Infinity Cache (tools/kernel_cases.py).",
                "cases": cases}, open(os.path.join(P, "%s_kernel_cases.json" % tag), "w"), indent=1, sort_keys=True)
-for name in ("bench_short.json", "bench_short2.json", "train_rccl_world1.json", "train_2ranks_share_device.json"):
+for name in ("bench_short.json", "bench_short2.json", "train_rccl_world1.json", "train_2ranks_share_device.json",
+             "selftest_rccl_world1.json", "selftest_8ranks_share_device.json"):
     src = os.path.join(G, "%s_%s" % (tag, name))
     if os.path.exists(src):
         js = [l for l in open(src) if l.startswith("{")]
         if js:
             json.dump(json.loads(js[-1]), open(os.path.join(P, "%s_%s" % (tag, name)), "w"), indent=1)
-for name in ("perf_guard.json", "clock_timeline.txt", "valu_rate.txt", "gputest.txt", "tolerance_uses.txt"):
+for name in ("perf_guard.json", "clock_timeline.txt", "valu_rate.txt", "gputest.txt", "tolerance_uses.txt", "copy_peak.txt",
+             "k3_placement_tim.txt", "k3_placement_tim0.txt"):
     src = os.path.join(G, "%s_%s" % (tag, name))
     if os.path.exists(src):
         keep = [l for l in open(src) if "amdgpu.ids" not in l]
