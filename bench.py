@@ -44,7 +44,9 @@ import torch  # noqa: E402
 
 T_IMPORTED = time.perf_counter()
 
-HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from bench_secondary import HBM_PEAK_GBPS, copy_peak, replayed_counters, secondary_kernels  # noqa: E402,F401  (untimed legs)
+
 FP32_VALU_PEAK_TFLOPS = 157.3   # ditto, packed-FMA vector peak
 FLOP_PER_PIXEL_SCENE = 573.0    # SURVEY.md 8d (div/sqrt/log/pow counted as 1)
 
@@ -210,251 +212,201 @@ def median_region_index(job_elapsed):
     return order[len(order) // 2]
 
 
-def replayed_counters(library, B, H, S, record_path=None):
-    """Hardware-counter figures of the headline kernel (HBM bytes, VALU instructions per launch) are NOT measured in a
-    bench run -- rocprofv3 --pmc needs its own passes (tools/collect_profiles.sh) -- but replayed from
-    profiles/k3_hbm_traffic.json.  A replay is honest only for the very code the counters were taken from: the record
-    carries the sha256 of the kernel's instruction bytes (svbrdf_estimation_amd/_codehash.py) and is replayed only when the
-    kernel inside `library` hashes to it and the shape is the recorded one.
-    -> (hbm bytes per launch | None, what was done and why (str) | None, the record (dict) when replayed else None)"""
-    import hashlib
-    path = record_path or os.path.join(ROOT, "profiles", "k3_hbm_traffic.json")
-    if not os.path.exists(path):
-        return None, None, None
-    try:
-        with open(path, "rb") as f:
-            raw = f.read()
-        tj = json.loads(raw.decode())
-        if not (tj.get("B") == B and tj.get("H") == H and tj.get("S") == S):
-            return None, "NOT replayed: %s holds the shape B=%s H=%s S=%s" % (os.path.basename(path), tj.get("B"), tj.get("H"), tj.get("S")), None
-        from svbrdf_estimation_amd import _codehash
-        try:
-            have = _codehash.k3_headline_hash(library)["sha256"]
-        except Exception as e:
-            have = "unreadable (%r)" % (e,)
-        if not tj.get("kernel_code_sha256") or tj["kernel_code_sha256"] != have:
-            return None, ("NOT replayed: profiles/k3_hbm_traffic.json holds counters of kernel code sha256 %s, the kernel in %s "
-                          "is %s -- re-record them (tools/collect_profiles.sh + summarize_profiles.py)"
-                          % (str(tj.get("kernel_code_sha256"))[:16], os.path.basename(library), have[:16])), None
-        return (tj.get("hbm_bytes_per_launch"),
-                "NOT measured in this run: PMC counters of the same kernel and shape recorded with rocprofv3 --pmc by "
-                "tools/collect_profiles.sh, replayed from profiles/k3_hbm_traffic.json (sha1 %s, build %s, kernel code sha256 "
-                "%s = this library's)" % (hashlib.sha1(raw).hexdigest()[:12], tj.get("git_head", "?"), have[:16]), tj)
-    except Exception as e:
-        return None, "NOT replayed: %r" % (e,), None
+MEASURED_KEYS = (
+    "B", "H", "S", "world", "n_batches", "elapsed", "job_elapsed", "median_region", "n_regions", "kernel_ms",
+    "kernel_ms_avg", "region_ms_per_launch", "main_ns", "timed_fast", "clock_ghz", "clock_note", "cycle_leg_ms",
+    "other_ms_per_step", "other_ms", "other_steps", "leg_steps", "leaf_ms_per_step", "engine_ms_per_step",
+    "engine_plain_ms_per_step", "copy", "mean_loss", "per_rank", "ranks_seen", "process_group", "host_path",
+)
 
 
-def synthetic_maps_on_device(dev, seed, B, H, rough_min=0.0, tied=True):
-    """synthetic_maps' distribution, drawn by the device generator: for the untimed secondary legs, whose 288-map working
-    sets take seconds to draw on the host (the headline inputs stay host-drawn and seeded per rank)"""
-    gen = torch.Generator(device=dev).manual_seed(seed)
-    n = torch.randn(B, 3, H, H, generator=gen, device=dev) * 0.3
-    n[:, 2] = 1.0 + n[:, 2].abs()
-    n = n / n.norm(dim=1, keepdim=True)
-    d = torch.rand(B, 3, H, H, generator=gen, device=dev)
-    r = torch.rand(B, 1 if tied else 3, H, H, generator=gen, device=dev).expand(B, 3, H, H) * (1.0 - rough_min) + rough_min
-    s = torch.rand(B, 3, H, H, generator=gen, device=dev)
-    return torch.cat((n, d, r, s), dim=1).contiguous()
-
-
-def _event_timed(fn, reps, dev, warm=3):
-    """average ms per call of `fn` over `reps` back-to-back calls, HIP events on the current stream (the launch stream)"""
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize(dev)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        fn()
-    b.record()
-    torch.cuda.synchronize(dev)
-    return a.elapsed_time(b) / reps
-
-
-def copy_peak(dev, gib=1.0):
-    """"report fraction of both nominal and measured-copy peak" -- the copy bandwidth of THIS box, measured in
-    this run: svbrdf_debug_copy (float4 streaming copy, non-temporal) on `gib` GiB -> `gib` GiB, far beyond the 256 MiB
-    Infinity Cache; bytes moved = read + written.  Best of three 10-launch regions."""
+def assemble_line(args, m):
+    """The JSON line from what main() measured (`m`: one value per MEASURED_KEYS).  Pure arithmetic and wording -- no GPU, no
+    timing -- so the contract's identities (value x ms_per_step = patches per step; roofline.frac x peak x ms_per_step =
+    algorithmic bytes; every follow-up figure None under --timed-only) are unit-tested on the CPU with made-up measurements
+    (tests/test_bench_contract.py)."""
     from svbrdf_estimation_amd import _native
-    n = int(gib * 2 ** 30) // 4
-    src = torch.empty(n, device=dev).uniform_(-1.0, 1.0)
-    dst = torch.empty_like(src)
-    ms = min(_event_timed(lambda: _native.debug_copy(dst, src), 10, dev) for _ in range(3))
-    ok = bool(torch.equal(src, dst))
-    del src, dst
-    return {"GBps": 8.0 * n / (ms * 1e-3) / 1e9, "ms_per_launch": ms, "bytes_moved_per_launch": 8.0 * n, "copied_correctly": ok,
-            "kernel": "svbrdf_debug_copy: k_copy_vec4<1, nontemporal>, %.0f MiB read + %.0f MiB written per launch"
-                      % (4.0 * n / 2 ** 20, 4.0 * n / 2 ** 20)}
+    (
+        B, H, S, world, n_batches, elapsed, job_elapsed, median_region, n_regions, kernel_ms, kernel_ms_avg,
+        region_ms_per_launch, main_ns, timed_fast, clock_ghz, clock_note, cycle_leg_ms, other_ms_per_step, other_ms,
+        other_steps, leg_steps, leaf_ms_per_step, engine_ms_per_step, engine_plain_ms_per_step, copy, mean_loss,
+        per_rank, ranks_seen, process_group, host_path
+    ) = (m[k] for k in MEASURED_KEYS)
+    patches = world * B * args.steps
+    ms_per_step = 1e3 * elapsed / args.steps      # THE interval of the headline: value, roofline.achieved and frac
+    alg_bytes = 144.0 * H * H * B                 # per launch: 36 planes x 4 B per patch (SURVEY 8d)
+    n_streams = max(1, main_ns)
+    follow_up = "follow-up leg of rank 0, same process and tensors, right after the timed region"
+    # the two ways of issuing the steps, whichever of them was the timed region
+    if main_ns == 0:
+        one = {"ms_per_step": ms_per_step, "kernel_ms": kernel_ms, "steps": args.steps, "leg": "the timed region"}
+        two = {"ms_per_step": other_ms_per_step, "kernel_ms": other_ms, "steps": other_steps, "streams": 2, "leg": follow_up}
+    else:
+        one = {"ms_per_step": other_ms_per_step, "kernel_ms": other_ms, "steps": other_steps, "leg": follow_up}
+        two = {"ms_per_step": ms_per_step, "kernel_ms": kernel_ms, "steps": args.steps, "streams": main_ns,
+               "leg": "the timed region"}
 
+    def rate(ms, n=1):          # patches/s of n GPUs at `ms` per step; None when the leg did not run (--timed-only)
+        return n * B / (ms * 1e-3) if ms else None
 
-def secondary_kernels(dev, H, copy_gbps):
-    """K1 / K2 alone at one render per map with a working set far beyond the 256 MiB Infinity Cache
-    (288 renders: 1.1 GB / 2.0 GB per launch): the HBM-bound kernels of the engine, for the record, against the nominal
-    8 TB/s and against the copy bandwidth measured in this run (`copy_gbps`)."""
-    from svbrdf_estimation_amd import _native, environment
-
-    def hbm(gbps):
-        return {"algorithmic_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
-                "frac_of_measured_copy_peak": gbps / copy_gbps if copy_gbps else None}
-    B = 288
-    maps = synthetic_maps_on_device(dev, 7, B, H)
-    torch.manual_seed(7)
-    table = environment.BatchSceneSampler(B, 1, 0).sample().to(dev)
-    cot = torch.randn(B, 1, 3, H, H, device=dev)
-    out = {}
-    for name, fn, nbytes in (("K1_render_fwd", lambda: _native.render_fwd(maps, table), 60.0 * H * H * B),
-                             ("K2_render_bwd", lambda: _native.render_bwd(maps, table, cot), 108.0 * H * H * B)):
-        ms = _event_timed(fn, 10, dev)
-        out[name] = dict({"renders_per_launch": B, "ms_per_launch": ms, "renders_per_s": B / (ms * 1e-3)},
-                         **hbm(nbytes / (ms * 1e-3) / 1e9))
-    # K1 with the sensor-noise epilogue (svbrdf_render_inputs: + sigma * N(0,1), clamp): one photo per map, same bytes
-    levels = torch.full((B, 1), 0.005, device=dev)
-    ms = _event_timed(lambda: _native.render_inputs(maps, table, levels, 1, 4), 10, dev)
-    out["K1_render_inputs_noise_clamp"] = dict({"photos_per_launch": B, "ms_per_launch": ms, "photos_per_s": B / (ms * 1e-3)},
-                                               **hbm(60.0 * H * H * B / (ms * 1e-3) / 1e9))
-    del maps, cot, levels
-    # K3 alone (kernel-limited rates, SURVEY 8d): sensitivity to the roughness distribution at config 2, the
-    # three-lobe path (independent roughness channels), and config 5 (512x512, 11 + 21 scenes)
-    def k3(tag, B, Hk, n_random, n_specular, **kw):
-        a, t = synthetic_maps_on_device(dev, 11, B, Hk, **kw), synthetic_maps_on_device(dev, 12, B, Hk, **kw)
-        torch.manual_seed(11)
-        tab = environment.BatchSceneSampler(B, n_random, n_specular).sample()
-        tab = tab if B * (n_random + n_specular) <= _native.host_scenes_max_rows() else tab.to(dev)
-        call = lambda: _native.rendering_loss(a, t, tab, 0.1, want_grad=True)
-        t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < 0.2:
-            for _ in range(20):
-                call()
-            torch.cuda.synchronize(dev)
-        # the ctypes binding costs ~50 us of host time per call, more than the kernel at config 2: events around EVERY
-        # launch give the kernel's own duration (median), the wall time of the loop the call rate of this binding
-        pairs = []
-        t0 = time.perf_counter()
-        for _ in range(30):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            call()
-            e1.record()
-            pairs.append((e0, e1))
-        torch.cuda.synchronize(dev)
-        wall_ms = 1e3 * (time.perf_counter() - t0) / 30
-        ms = sorted(p[0].elapsed_time(p[1]) for p in pairs)[len(pairs) // 2]
-        gb = 144.0 * Hk * Hk * B / (ms * 1e-3) / 1e9
-        out[tag] = {"B": B, "H": Hk, "scenes": n_random + n_specular, "ms_per_launch": ms,
-                    "ms_per_call_wall_ctypes_binding": wall_ms,
-                    "patches_per_s": B / (ms * 1e-3), "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBPS}
-    def k3_module(tag, B, Hk, loss_fn, n_streams):
-        """whole steps through the module interface (host path, autograd), like the headline loop"""
-        sets = [(synthetic_maps_on_device(dev, 13 + 2 * q, B, Hk).requires_grad_(True), synthetic_maps_on_device(dev, 14 + 2 * q, B, Hk))
-                for q in range(4)]
-        sts = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else None
-        torch.cuda.synchronize(dev)
-
-        def run(n):
-            for k in range(n):
-                if sts:
-                    torch.cuda.set_stream(sts[k % n_streams])
-                a, t = sets[k % 4]
-                a.grad = None
-                loss_fn(a, t).backward()
-        # settle by TIME, not by step count: right after the host-side generation of a new batch size the first ~100 ms of a
-        # leg have been seen running 3-4x slow (host-bound: the intra-op pool's workers still spinning, see main())
-        t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < 0.3:
-            run(60)
-            torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        run(300)
-        torch.cuda.synchronize(dev)
-        ms = 1e3 * (time.perf_counter() - t0) / 300
-        torch.cuda.set_stream(torch.cuda.default_stream(dev))
-        gb = 144.0 * Hk * Hk * B / (ms * 1e-3) / 1e9
-        out[tag] = {"B": B, "H": Hk, "streams": n_streams, "ms_per_step": ms, "patches_per_s": B / (ms * 1e-3),
-                    "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBPS}
-    from svbrdf_estimation_amd import losses, renderers, synthesis
-
-    # SURVEY 8d's secondary metric: renders/s THROUGH the plugin interface, `LocalRenderer().render(scene, svbrdf)`
-    # (renderers.py:67-104), one reference-shaped call after the other: a Scene object of python lists, one [12,H,W]
-    # map (-> [1,3,H,W]) or a [8,12,H,W] batch with the one scene; forward, and forward + backward of a cotangent.
-    # The call is one dispatch (the scene's nine floats ride in the launch's argument block), so with a 256x256 map it is
-    # host-bound: us_per_call is host time.
-    R = renderers.LocalRenderer()
-    scene = environment.Scene(environment.Camera([0.1, -0.2, 2.0]), environment.Light([0.4, 0.3, 1.5], [30.0, 30.0, 30.0]))
-    for tag, nb in (("LocalRenderer_render_one_map", 0), ("LocalRenderer_render_batch8", 8)):
-        m = synthetic_maps_on_device(dev, 17 + nb, max(nb, 1), H)
-        m = m if nb else m[0]
-        cot = torch.randn(max(nb, 1), 3, H, H, device=dev)
-        x = m.clone().requires_grad_(True)
-        res = {}
-        for mode in ("fwd", "fwd_bwd"):
-            def call():
-                if mode == "fwd":
-                    R.render(scene, m)
-                else:
-                    x.grad = None
-                    R.render(scene, x).backward(cot)
-            t_settle = time.perf_counter()          # settle by time (see k3_module below)
-            while time.perf_counter() - t_settle < 0.3:
-                for _ in range(50):
-                    call()
-                torch.cuda.synchronize(dev)
-            n = 500
-            t0 = time.perf_counter()
-            for _ in range(n):
-                call()
-            host_s = time.perf_counter() - t0        # the host's share: every call issued, the GPU still working
-            torch.cuda.synchronize(dev)
-            wall = time.perf_counter() - t0
-            res[mode] = {"renders_per_s": n * max(nb, 1) / wall, "us_per_call": 1e6 * wall / n,
-                         "host_us_per_call": 1e6 * host_s / n}
-        res["maps_per_call"] = max(nb, 1)
-        out[tag] = res
-    # the dataloader's call shape served on the GPU (round 6): a HOST [1,12,H,W] map in, a HOST photo out (dataset.py:206-212:
-    # pinned round trip around K1), PCIe-inclusive by construction
-    host_map = synthetic_maps_on_device(dev, 19, 1, H).cpu()
-    for _ in range(5):
-        R.render(scene, host_map)
-    t0, n = time.perf_counter(), 200
-    for _ in range(n):
-        R.render(scene, host_map)
-    dt = (time.perf_counter() - t0) / n
-    out["LocalRenderer_render_host_tensor"] = {
-        "renders_per_s": 1.0 / dt, "us_per_call": 1e6 * dt,
-        "note": "CPU tensor in, CPU tensor out (the reference dataloader's call): host copy into pinned memory, H2D, K1, D2H, "
-                "event wait, clone -- 3.0 MiB up and 0.75 MiB down over PCIe per call"}
-    # K4 (material mixing, dataset.py:142-160) and the input-photo synthesis on K1 (dataset.py:162-221), per call
-    Bm = 64
-    a, b = synthetic_maps_on_device(dev, 21, Bm, H), synthetic_maps_on_device(dev, 22, Bm, H)
-    alpha = torch.rand(Bm, device=dev) * 0.8 + 0.1
-    ms = _event_timed(lambda: _native.mix_materials(a, b, alpha), 20, dev)
-    out["K4_mix_materials"] = dict({"samples_per_launch": Bm, "ms_per_launch": ms, "samples_per_s": Bm / (ms * 1e-3),
-                                    "working_set_MiB": 36.0 * H * H * 4 * Bm / 2 ** 20}, **hbm(144.0 * H * H * Bm / (ms * 1e-3) / 1e9))
-    for views, Bs in ((1, 8), (5, 16)):
-        sv = a[:Bs]
-        for _ in range(3):
-            synthesis.render_inputs(sv, views)
-        torch.cuda.synchronize(dev)
-        launches = _native.launch_count()
-        t0, n = time.perf_counter(), 30
-        for _ in range(n):
-            synthesis.render_inputs(sv, views)
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / n
-        out["render_inputs_B%d_views%d" % (Bs, views)] = {
-            "photos_per_s": Bs * views / dt, "ms_per_call": 1e3 * dt,
-            "kernel_launches_per_call": (_native.launch_count() - launches) / n,
-            "note": "scene draws on the host in the reference's order + ONE launch of K1 with the noise + clamp epilogue "
-                    "(svbrdf_render_inputs_host_scenes), whole batch; host-bound on the per-sample scene draws"}
-    del a, b
-    mixed = losses.MixedLoss(renderers.LocalRenderer())
-    # BASELINE configs[3]: batch 16, mixed loss (the multi-view network's output has the same loss shapes); its 144 scene
-    # rows ride in the launch's argument block like config 2's 72
-    k3_module("K3_config4_B16_mixed_loss", 16, H, mixed, 1)
-    k3_module("K3_config4_B16_mixed_loss_2streams", 16, H, mixed, 2)
-    k3("K3_config2_roughness_U(0.2,1)", 8, H, 3, 6, rough_min=0.2)
-    k3("K3_config2_untied_roughness", 8, H, 3, 6, tied=False)
-    k3("K3_config5_512_32scenes", 8, 512, 11, 21)
-    return out
+    def avg(v):
+        return sum(v) / len(v) if v else None
+    one_kernel_avg, two_kernel_avg = avg(one["kernel_ms"]), avg(two["kernel_ms"])
+    # ONE clock: the roofline is priced with the interval `value` is priced with (wall time of the median region, MAX
+    # over ranks, / steps): frac x peak x ms_per_step / bytes == 1.  What rounds 1-5 priced it with -- the HIP event
+    # pair around the region on the launch stream / launches, 2-3 % shorter (no barrier, no synchronize, no host tail) --
+    # stays beside it as time_per_launch_ms / frac_by_launch_events.
+    achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9
+    events_ms = region_ms_per_launch if n_streams == 1 else None
+    achieved_events = alg_bytes / (events_ms * 1e-3) / 1e9 if events_ms else None
+    achieved_two = alg_bytes / (two["ms_per_step"] * 1e-3) / 1e9 if two["ms_per_step"] else None
+    copy_gbps = copy.get("GBps") if copy else None
+    valu_issue = None
+    traffic, traffic_source, tj = replayed_counters(_native.library_path(), B, H, S)
+    cycle_ms = cycle_leg_ms or events_ms or ms_per_step
+    if tj is not None and tj.get("valu_wave_instr_per_launch") and clock_ghz:
+        # what actually bounds K3: wave64 VALU instructions issued (PMC SQ_INSTS_VALU of the same
+        # kernel, profiles/) against the SIMD-32 issue peak of one per 2 cycles per SIMD
+        # (MI355X_MICROARCH.md), 1024 SIMDs, at the clock the chip holds under the loop
+        peak = 1024 * clock_ghz * 1e9 / 2.0
+        issue_rate = tj["valu_wave_instr_per_launch"] / (cycle_ms * 1e-3)      # duration of the clock's own interval
+        valu_issue = {"wave_instr_per_launch": tj["valu_wave_instr_per_launch"],
+                      "of_which_transcendental": tj.get("trans_wave_instr_per_launch"),
+                      "instr_count_source": traffic_source,
+                      "achieved_wave_instr_per_s": issue_rate, "peak_wave_instr_per_s": peak,
+                      "frac": issue_rate / peak,
+                      # a transcendental holds the SIMD for 6.5 plain issue slots when several waves share
+                      # it (profiles/r01_valu_trans.txt: 4 rcp + 28 mul vs 32 mul, 4 waves per SIMD)
+                      "frac_transcendental_weighted":
+                          (issue_rate / peak) * (1.0 + 5.5 * tj["trans_wave_instr_per_launch"] / tj["valu_wave_instr_per_launch"])
+                          if tj.get("trans_wave_instr_per_launch") else None,
+                      "clock_GHz_under_load": clock_ghz, "clock_source": clock_note}
+    working_set = n_batches * (2 * 12 + 12) * H * H * B * 4
+    timed_is = ("loss.backward() through PyTorch's autograd engine (what a network output gets: the training-loop figure; one "
+                "kernel launch per step)" if not timed_fast else
+                "the engine-free accumulate a plain loss.backward() on a LEAF input resolves to (--backward leaf)")
+    value_leaf = rate(leaf_ms_per_step, world)
+    value_engine = patches / elapsed if not timed_fast else rate(engine_ms_per_step, world)
+    out = {
+        "metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)",
+        "value": patches / elapsed, "unit": "patches/s", "n_gpus": world,
+        "per_gpu_value": patches / elapsed / world,
+        "value_is": timed_is,
+        # the same figure under its round-5 name (then a follow-up leg; since round 6 it IS the timed region)
+        "value_through_autograd_engine": value_engine,
+        "value_leaf_shortcut": value_leaf if not timed_fast else patches / elapsed,
+        "value_through_autograd_engine_with_fill_and_scale_launches": rate(engine_plain_ms_per_step, world),
+        "valu_issue_frac": valu_issue["frac"] if valu_issue else None,      # what bounds K3 (also in roofline, with its inputs)
+        "value_single_stream": rate(one["ms_per_step"], world),
+        "value_two_streams_overlapped": rate(two["ms_per_step"], world),
+        "follow_up_legs": "skipped (--timed-only)" if args.timed_only else "run",
+        "copy_peak_GBps_measured": copy_gbps,
+        "timed_regions": {"count": n_regions, "steps_each": args.steps, "median_index": median_region,
+                          "ms_per_step": [1e3 * e / args.steps for e in job_elapsed],
+                          "value": [world * B * args.steps / e for e in job_elapsed],
+                          "spread_max_minus_min_over_median": (max(job_elapsed) - min(job_elapsed)) / elapsed,
+                          "note": "each region: exactly `steps` steps between barrier + synchronize on both sides, MAX over "
+                                  "ranks; `value`, `ms_per_step` and the roofline are the MEDIAN region's" if n_regions > 1 else
+                                  "one region (the form with >= 256 steps)"},
+        "value_note": (("`value` = the MEDIAN of %d consecutive timed regions of %d steps each (all listed in timed_regions); "
+                        % (n_regions, args.steps)) if n_regions > 1 else "") +
+                      "`value` = patches / wall time of the timed region: every step on %s, %s.  roofline.achieved and "
+                      "roofline.frac are priced with the same interval (ms_per_step).  Untimed follow-up legs of the same "
+                      "process: value_leaf_shortcut = %s; value_two_streams_overlapped = independent steps alternating on "
+                      "two streams (a bench-loop property, not a training loop's)"
+                      % ("ONE stream" if main_ns == 0 else "%d streams" % main_ns, timed_is,
+                         "the engine-free accumulate of a LEAF input (rounds 1-5's `value`)" if not timed_fast else
+                         "this region itself (see value_through_autograd_engine for the engine)"),
+        "ranks_seen": ranks_seen,       # summed by the bring-up all-reduce itself, not read from the environment
+        "process_group": process_group,
+        "per_rank": per_rank,
+        "launch": "self-spawned" if os.environ.get("SVBRDF_SELF_SPAWNED") else
+                  ("external launcher" if world > 1 else "single process"),
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: synthetic %dx%d 12-channel SVBRDF maps, %d light/view "
+                               "samples (%d random + %d specular), per-GPU batch %d, RenderingLoss fwd+bwd, %s"
+                               % (H, H, S, args.random_scenes, args.specular_scenes, B,
+                                  "one step at a time on one stream" if main_ns == 0 else
+                                  "TWO INDEPENDENT BATCHES IN FLIGHT: steps alternate on %d streams" % main_ns),
+                   "global_batch": world * B, "H": H, "W": H, "scenes": S,
+                   "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                   "streams_per_gpu": n_streams,
+                   "backward": "autograd engine" if not timed_fast else "leaf shortcut",
+                   "distinct_batches": n_batches,
+                   "working_set_MiB": working_set / 2.0 ** 20,
+                   "working_set_note": "input + target + gradient of every batch visited round-robin; the Infinity "
+                                       "Cache holds 256 MiB"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "time_per_step_ms": ms_per_step,          # = ms_per_step: the interval achieved / frac are priced with
+                     "achieved_definition": "algorithmic bytes per launch (144*H*W*B) / ms_per_step of the (median) timed "
+                                            "region -- the interval `value` is priced with; one launch per step",
+                     # secondary: the HIP event pair around the same region on the launch stream / launches (rounds 1-5's
+                     # pricing; excludes the barrier / synchronize / host tail of the region: 2-3 % shorter)
+                     "time_per_launch_ms": events_ms,
+                     "frac_by_launch_events": achieved_events / HBM_PEAK_GBPS if achieved_events else None,
+                     # against the copy bandwidth this box reached in this run (svbrdf_debug_copy, 1 GiB each way)
+                     "copy_peak_GBps_measured": copy_gbps,
+                     "frac_of_measured_copy_peak": achieved / copy_gbps if copy_gbps else None,
+                     "copy_peak": copy,
+                     # flat copies of what the nested objects below hold (a line parser that keeps scalars keeps these)
+                     "valu_issue_frac": valu_issue["frac"] if valu_issue else None,
+                     "valu_issue_clock_GHz": valu_issue["clock_GHz_under_load"] if valu_issue else None,
+                     # boxes (and builds: the chip lowers its clock as the issue stream gets denser) differ in clock by
+                     # 5-15 %; launch duration x the clock measured in this run is the box-independent figure
+                     "shader_cycles_per_launch": (cycle_ms * 1e-3 * clock_ghz * 1e9) if clock_ghz else None,
+                     "shader_cycles_leg_ms_per_launch": cycle_leg_ms,    # the interval the clock was read in (untimed follow-up leg)
+                     "valu_issue_wave_instr_per_launch": valu_issue["wave_instr_per_launch"] if valu_issue else None,
+                     "kernel": "%s<GRAD=true,L1=false,HEAD=false> (single launch: both shadings, log/L1, adjoint, loss finalise)"
+                               % ("k_rendering_loss_inl" if B * S <= _native.host_scenes_max_rows() else "k_rendering_loss"),
+                     "scene_table": "by value in the kernel-argument block (no H2D command)"
+                                    if B * S <= _native.host_scenes_max_rows() else "pinned-ring upload",
+                     "launches_in_flight": n_streams,
+                     # event pairs around a SAMPLE of single launches (dispatch gap + kernel + event bubble each): evidence
+                     # that a launch is what fills a step, never what the roofline is priced with
+                     "kernel_launches_timed": len(kernel_ms),
+                     "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
+                     "kernel_ms_note": "pairs bracket every 32nd launch of the timed region (a region shorter than 256 steps: "
+                                       "every 16th of an untimed 512-step leg right after it); a pair spans the ~3 us dispatch "
+                                       "gap in front of the launch and its own end-of-pipe bubble, so it reads longer than "
+                                       "ms_per_step",
+                     "valu_frac_of_fp32_peak": (FLOP_PER_PIXEL_SCENE * H * H * S * B / (ms_per_step * 1e-3))
+                                               / (FP32_VALU_PEAK_TFLOPS * 1e12),
+                     "valu_issue": valu_issue},
+        "single_stream": {"patches_per_s": rate(one["ms_per_step"]), "ms_per_step": one["ms_per_step"],
+                          "kernel_ms_avg": one_kernel_avg,
+                          "kernel_ms_median": one["kernel_ms"][len(one["kernel_ms"]) // 2] if one["kernel_ms"] else None,
+                          "kernel_launches_timed": len(one["kernel_ms"]), "steps": one["steps"], "leg": one["leg"]},
+        "two_streams_overlapped": {"patches_per_s": rate(two["ms_per_step"]), "ms_per_step": two["ms_per_step"],
+                                   "streams": two["streams"], "kernel_ms_avg_while_overlapped": two_kernel_avg,
+                                   "steps": two["steps"], "leg": two["leg"],
+                                   "roofline_frac_of_time_share": achieved_two / HBM_PEAK_GBPS if achieved_two else None,
+                                   "note": "per GPU: step k (launch + backward) on stream k mod 2; the steps are independent "
+                                           "batches, so one step's kernel fills the ramp and tail of the other's.  A "
+                                           "bench-loop property: not what one training loop gets"},
+        "backward_modes": {
+            "timed_region": "engine" if not timed_fast else "leaf shortcut",
+            "engine_one_launch_per_step": {"patches_per_s": rate(engine_ms_per_step), "ms_per_step": engine_ms_per_step},
+            "engine_with_fill_and_scale_launches": {"patches_per_s": rate(engine_plain_ms_per_step),
+                                                    "ms_per_step": engine_plain_ms_per_step},
+            "leaf_shortcut": {"patches_per_s": rate(leaf_ms_per_step), "ms_per_step": leaf_ms_per_step}
+                             if leaf_ms_per_step else ("not run" if args.timed_only else "not available on this torch version"),
+            "steps_each": leg_steps,
+            "note": "per GPU, untimed follow-up legs on one stream, HIP events around each.  engine_one_launch_per_step: the "
+                    "engine is handed the extension's cached device-resident 1.0 and the node, recognising it by address and "
+                    "version, skips its scale launch (the timed region's mode by default); ..._with_fill_and_scale_launches: "
+                    "the engine's own ones-fill kernel and the node's no-op scale launch, as in rounds 1-4 (three kernels); "
+                    "leaf_shortcut: input.grad (+)= the buffer the kernel wrote, no engine (a LEAF input only: the notebooks' "
+                    "direct map optimisation, rounds 1-5's bench loop)"},
+        "loss": mean_loss,
+        "host_path": host_path,
+        "autograd_engine": "multithreaded" if args.engine_threads else "calling thread",
+        "settle_ms": args.settle_ms,
+    }
+    return out, copy_gbps
 
 
 def plumbing_only(args, rank, world, placement):
@@ -846,181 +798,17 @@ def main():
                 copy = {"GBps": None, "error": repr(e)}
 
     if rank == 0:
-        patches = world * B * args.steps
-        ms_per_step = 1e3 * elapsed / args.steps      # THE interval of the headline: value, roofline.achieved and frac
-        alg_bytes = 144.0 * H * H * B                 # per launch: 36 planes x 4 B per patch
-        n_streams = max(1, main_ns)
-        follow_up = "follow-up leg of rank 0, same process and tensors, right after the timed region"
-        # the two ways of issuing the steps, whichever of them was the timed region
-        if main_ns == 0:
-            one = {"ms_per_step": ms_per_step, "kernel_ms": kernel_ms, "steps": args.steps, "leg": "the timed region"}
-            two = {"ms_per_step": other_ms_per_step, "kernel_ms": other_ms, "steps": other_steps, "streams": 2, "leg": follow_up}
-        else:
-            one = {"ms_per_step": other_ms_per_step, "kernel_ms": other_ms, "steps": other_steps, "leg": follow_up}
-            two = {"ms_per_step": ms_per_step, "kernel_ms": kernel_ms, "steps": args.steps, "streams": main_ns,
-                   "leg": "the timed region"}
-
-        def rate(ms, n=1):          # patches/s of n GPUs at `ms` per step; None when the leg did not run (--timed-only)
-            return n * B / (ms * 1e-3) if ms else None
-
-        def avg(v):
-            return sum(v) / len(v) if v else None
-        one_kernel_avg, two_kernel_avg = avg(one["kernel_ms"]), avg(two["kernel_ms"])
-        # ONE clock: the roofline is priced with the interval `value` is priced with (wall time of the median region, MAX
-        # over ranks, / steps): frac x peak x ms_per_step / bytes == 1.  What rounds 1-5 priced it with -- the HIP event
-        # pair around the region on the launch stream / launches, 2-3 % shorter (no barrier, no synchronize, no host tail) --
-        # stays beside it as time_per_launch_ms / frac_by_launch_events.
-        achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9
-        events_ms = region_ms_per_launch if n_streams == 1 else None
-        achieved_events = alg_bytes / (events_ms * 1e-3) / 1e9 if events_ms else None
-        achieved_two = alg_bytes / (two["ms_per_step"] * 1e-3) / 1e9 if two["ms_per_step"] else None
-        copy_gbps = copy.get("GBps") if copy else None
-        valu_issue = None
-        traffic, traffic_source, tj = replayed_counters(_native.library_path(), B, H, S)
-        cycle_ms = cycle_leg_ms or events_ms or ms_per_step
-        if tj is not None and tj.get("valu_wave_instr_per_launch") and clock_ghz:
-            # what actually bounds K3: wave64 VALU instructions issued (PMC SQ_INSTS_VALU of the same
-            # kernel, profiles/) against the SIMD-32 issue peak of one per 2 cycles per SIMD
-            # (MI355X_MICROARCH.md), 1024 SIMDs, at the clock the chip holds under the loop
-            peak = 1024 * clock_ghz * 1e9 / 2.0
-            rate = tj["valu_wave_instr_per_launch"] / (cycle_ms * 1e-3)      # duration of the clock's own interval
-            valu_issue = {"wave_instr_per_launch": tj["valu_wave_instr_per_launch"],
-                          "of_which_transcendental": tj.get("trans_wave_instr_per_launch"),
-                          "instr_count_source": traffic_source,
-                          "achieved_wave_instr_per_s": rate, "peak_wave_instr_per_s": peak,
-                          "frac": rate / peak,
-                          # a transcendental holds the SIMD for 6.5 plain issue slots when several waves share
-                          # it (profiles/r01_valu_trans.txt: 4 rcp + 28 mul vs 32 mul, 4 waves per SIMD)
-                          "frac_transcendental_weighted":
-                              (rate / peak) * (1.0 + 5.5 * tj["trans_wave_instr_per_launch"] / tj["valu_wave_instr_per_launch"])
-                              if tj.get("trans_wave_instr_per_launch") else None,
-                          "clock_GHz_under_load": clock_ghz, "clock_source": clock_note}
-        working_set = len(batches) * (2 * 12 + 12) * H * H * B * 4
-        timed_is = ("loss.backward() through PyTorch's autograd engine (what a network output gets: the training-loop figure; one "
-                    "kernel launch per step)" if not timed_fast else
-                    "the engine-free accumulate a plain loss.backward() on a LEAF input resolves to (--backward leaf)")
-        value_leaf = rate(leaf_ms_per_step, world)
-        value_engine = patches / elapsed if not timed_fast else rate(engine_ms_per_step, world)
-        out = {
-            "metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)",
-            "value": patches / elapsed, "unit": "patches/s", "n_gpus": world,
-            "per_gpu_value": patches / elapsed / world,
-            "value_is": timed_is,
-            # the same figure under its round-5 name (then a follow-up leg; since round 6 it IS the timed region)
-            "value_through_autograd_engine": value_engine,
-            "value_leaf_shortcut": value_leaf if not timed_fast else patches / elapsed,
-            "value_through_autograd_engine_with_fill_and_scale_launches": rate(engine_plain_ms_per_step, world),
-            "valu_issue_frac": valu_issue["frac"] if valu_issue else None,      # what bounds K3 (also in roofline, with its inputs)
-            "value_single_stream": rate(one["ms_per_step"], world),
-            "value_two_streams_overlapped": rate(two["ms_per_step"], world),
-            "follow_up_legs": "skipped (--timed-only)" if args.timed_only else "run",
-            "copy_peak_GBps_measured": copy_gbps,
-            "timed_regions": {"count": n_regions, "steps_each": args.steps, "median_index": median_region,
-                              "ms_per_step": [1e3 * e / args.steps for e in job_elapsed],
-                              "value": [world * B * args.steps / e for e in job_elapsed],
-                              "spread_max_minus_min_over_median": (max(job_elapsed) - min(job_elapsed)) / elapsed,
-                              "note": "each region: exactly `steps` steps between barrier + synchronize on both sides, MAX over "
-                                      "ranks; `value`, `ms_per_step` and the roofline are the MEDIAN region's" if n_regions > 1 else
-                                      "one region (the form with >= 256 steps)"},
-            "value_note": (("`value` = the MEDIAN of %d consecutive timed regions of %d steps each (all listed in timed_regions); "
-                            % (n_regions, args.steps)) if n_regions > 1 else "") +
-                          "`value` = patches / wall time of the timed region: every step on %s, %s.  roofline.achieved and "
-                          "roofline.frac are priced with the same interval (ms_per_step).  Untimed follow-up legs of the same "
-                          "process: value_leaf_shortcut = %s; value_two_streams_overlapped = independent steps alternating on "
-                          "two streams (a bench-loop property, not a training loop's)"
-                          % ("ONE stream" if main_ns == 0 else "%d streams" % main_ns, timed_is,
-                             "the engine-free accumulate of a LEAF input (rounds 1-5's `value`)" if not timed_fast else
-                             "this region itself (see value_through_autograd_engine for the engine)"),
-            "ranks_seen": ranks_seen,       # summed by the bring-up all-reduce itself, not read from the environment
+        out, copy_gbps = assemble_line(args, {
+            "B": B, "H": H, "S": S, "world": world, "n_batches": len(batches), "elapsed": elapsed, "job_elapsed": job_elapsed,
+            "median_region": median_region, "n_regions": n_regions, "kernel_ms": kernel_ms, "kernel_ms_avg": kernel_ms_avg,
+            "region_ms_per_launch": region_ms_per_launch, "main_ns": main_ns, "timed_fast": timed_fast, "clock_ghz": clock_ghz,
+            "clock_note": clock_note, "cycle_leg_ms": cycle_leg_ms, "other_ms_per_step": other_ms_per_step, "other_ms": other_ms,
+            "other_steps": other_steps, "leg_steps": leg_steps, "leaf_ms_per_step": leaf_ms_per_step,
+            "engine_ms_per_step": engine_ms_per_step, "engine_plain_ms_per_step": engine_plain_ms_per_step, "copy": copy,
+            "mean_loss": mean_loss, "per_rank": per_rank, "ranks_seen": ranks_seen,
             "process_group": ("%s (%s), world size %d" % (args.backend, "RCCL" if nccl else "CPU transport, plumbing only",
                                                           dist.get_world_size())) if dist is not None else None,
-            "per_rank": per_rank,
-            "launch": "self-spawned" if os.environ.get("SVBRDF_SELF_SPAWNED") else
-                      ("external launcher" if world > 1 else "single process"),
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic %dx%d 12-channel SVBRDF maps, %d light/view "
-                                   "samples (%d random + %d specular), per-GPU batch %d, RenderingLoss fwd+bwd, %s"
-                                   % (H, H, S, args.random_scenes, args.specular_scenes, B,
-                                      "one step at a time on one stream" if main_ns == 0 else
-                                      "TWO INDEPENDENT BATCHES IN FLIGHT: steps alternate on %d streams" % main_ns),
-                       "global_batch": world * B, "H": H, "W": H, "scenes": S,
-                       "parallelism": "batch-sharded x%d, no data-path collective" % world,
-                       "streams_per_gpu": n_streams,
-                       "backward": "autograd engine" if not timed_fast else "leaf shortcut",
-                       "distinct_batches": len(batches),
-                       "working_set_MiB": working_set / 2.0 ** 20,
-                       "working_set_note": "input + target + gradient of every batch visited round-robin; the Infinity "
-                                           "Cache holds 256 MiB"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "time_per_step_ms": ms_per_step,          # = ms_per_step: the interval achieved / frac are priced with
-                         "achieved_definition": "algorithmic bytes per launch (144*H*W*B) / ms_per_step of the (median) timed "
-                                                "region -- the interval `value` is priced with; one launch per step",
-                         # secondary: the HIP event pair around the same region on the launch stream / launches (rounds 1-5's
-                         # pricing; excludes the barrier / synchronize / host tail of the region: 2-3 % shorter)
-                         "time_per_launch_ms": events_ms,
-                         "frac_by_launch_events": achieved_events / HBM_PEAK_GBPS if achieved_events else None,
-                         # against the copy bandwidth this box reached in this run (svbrdf_debug_copy, 1 GiB each way)
-                         "copy_peak_GBps_measured": copy_gbps,
-                         "frac_of_measured_copy_peak": achieved / copy_gbps if copy_gbps else None,
-                         "copy_peak": copy,
-                         # flat copies of what the nested objects below hold (a line parser that keeps scalars keeps these)
-                         "valu_issue_frac": valu_issue["frac"] if valu_issue else None,
-                         "valu_issue_clock_GHz": valu_issue["clock_GHz_under_load"] if valu_issue else None,
-                         # boxes (and builds: the chip lowers its clock as the issue stream gets denser) differ in clock by
-                         # 5-15 %; launch duration x the clock measured in this run is the box-independent figure
-                         "shader_cycles_per_launch": (cycle_ms * 1e-3 * clock_ghz * 1e9) if clock_ghz else None,
-                         "shader_cycles_leg_ms_per_launch": cycle_leg_ms,    # the interval the clock was read in (untimed follow-up leg)
-                         "valu_issue_wave_instr_per_launch": valu_issue["wave_instr_per_launch"] if valu_issue else None,
-                         "kernel": "%s<GRAD=true,L1=false,HEAD=false> (single launch: both shadings, log/L1, adjoint, loss finalise)"
-                                   % ("k_rendering_loss_inl" if B * S <= _native.host_scenes_max_rows() else "k_rendering_loss"),
-                         "scene_table": "by value in the kernel-argument block (no H2D command)"
-                                        if B * S <= _native.host_scenes_max_rows() else "pinned-ring upload",
-                         "launches_in_flight": n_streams,
-                         # event pairs around a SAMPLE of single launches (dispatch gap + kernel + event bubble each): evidence
-                         # that a launch is what fills a step, never what the roofline is priced with
-                         "kernel_launches_timed": len(kernel_ms),
-                         "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
-                         "kernel_ms_note": "pairs bracket every 32nd launch of the timed region (a region shorter than 256 steps: "
-                                           "every 16th of an untimed 512-step leg right after it); a pair spans the ~3 us dispatch "
-                                           "gap in front of the launch and its own end-of-pipe bubble, so it reads longer than "
-                                           "ms_per_step",
-                         "valu_frac_of_fp32_peak": (FLOP_PER_PIXEL_SCENE * H * H * S * B / (ms_per_step * 1e-3))
-                                                   / (FP32_VALU_PEAK_TFLOPS * 1e12),
-                         "valu_issue": valu_issue},
-            "single_stream": {"patches_per_s": rate(one["ms_per_step"]), "ms_per_step": one["ms_per_step"],
-                              "kernel_ms_avg": one_kernel_avg,
-                              "kernel_ms_median": one["kernel_ms"][len(one["kernel_ms"]) // 2] if one["kernel_ms"] else None,
-                              "kernel_launches_timed": len(one["kernel_ms"]), "steps": one["steps"], "leg": one["leg"]},
-            "two_streams_overlapped": {"patches_per_s": rate(two["ms_per_step"]), "ms_per_step": two["ms_per_step"],
-                                       "streams": two["streams"], "kernel_ms_avg_while_overlapped": two_kernel_avg,
-                                       "steps": two["steps"], "leg": two["leg"],
-                                       "roofline_frac_of_time_share": achieved_two / HBM_PEAK_GBPS if achieved_two else None,
-                                       "note": "per GPU: step k (launch + backward) on stream k mod 2; the steps are independent "
-                                               "batches, so one step's kernel fills the ramp and tail of the other's.  A "
-                                               "bench-loop property: not what one training loop gets"},
-            "backward_modes": {
-                "timed_region": "engine" if not timed_fast else "leaf shortcut",
-                "engine_one_launch_per_step": {"patches_per_s": rate(engine_ms_per_step), "ms_per_step": engine_ms_per_step},
-                "engine_with_fill_and_scale_launches": {"patches_per_s": rate(engine_plain_ms_per_step),
-                                                        "ms_per_step": engine_plain_ms_per_step},
-                "leaf_shortcut": {"patches_per_s": rate(leaf_ms_per_step), "ms_per_step": leaf_ms_per_step}
-                                 if leaf_ms_per_step else ("not run" if args.timed_only else "not available on this torch version"),
-                "steps_each": leg_steps,
-                "note": "per GPU, untimed follow-up legs on one stream, HIP events around each.  engine_one_launch_per_step: the "
-                        "engine is handed the extension's cached device-resident 1.0 and the node, recognising it by address and "
-                        "version, skips its scale launch (the timed region's mode by default); ..._with_fill_and_scale_launches: "
-                        "the engine's own ones-fill kernel and the node's no-op scale launch, as in rounds 1-4 (three kernels); "
-                        "leaf_shortcut: input.grad (+)= the buffer the kernel wrote, no engine (a LEAF input only: the notebooks' "
-                        "direct map optimisation, rounds 1-5's bench loop)"},
-            "loss": mean_loss,
-            "host_path": "native C++ extension (csrc/host_ext.cpp)" if ext is not None else "python + ctypes",
-            "autograd_engine": "multithreaded" if args.engine_threads else "calling thread",
-            "settle_ms": args.settle_ms,
-        }
+            "host_path": "native C++ extension (csrc/host_ext.cpp)" if ext is not None else "python + ctypes"})
         t_main = time.perf_counter()
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_kernels(dev, H, copy_gbps)

@@ -12,7 +12,9 @@ reference's flat modules so a training script only changes its imports:
 not an importable Python identifier.)
 
 There is no CPU implementation in this package: every compute entry point raises if
-the HIP extension is missing or the tensors are not on a ROCm device.
+the HIP extension is missing or no ROCm device is there to compute on.  (A HOST tensor handed
+to ``LocalRenderer.render`` -- the reference dataloader's call -- is staged to the GPU and
+rendered there; the losses take device tensors only.)
 """
 from . import distributed, environment, losses, renderers, synthesis, utils  # noqa: F401
 from ._native import NativeLibraryError, library_path  # noqa: F401
@@ -38,10 +40,13 @@ def install(modules=None, patch_renderer=True):
     ``environment`` / ``utils`` / ``dataset`` / ``models`` stay the reference's.  ``modules`` (for tests): a dict
     {"renderers": module, "losses": module} to patch instead of importing by name.  Returns what it replaced.
 
-    ``patch_renderer=False`` leaves ``renderers.LocalRenderer`` the reference's: its CPU dataloader renders missing input
-    photos with it in the worker processes (dataset.py:206-212), where this engine has nothing to offer (no CPU path),
-    while the patched ``RenderingLoss`` / ``MixedLoss`` still take the fused kernel -- they recognise the reference's
-    ``LocalRenderer`` object as the renderer the kernels replace (``losses.RenderingLoss.uses_fused_kernel``)."""
+    The default serves ``main.py`` unchanged: the losses take the fused kernel, and the reference's dataloader call
+    ``LocalRenderer().render(scene, svbrdf.unsqueeze(0))`` with HOST tensors in the main process (dataset.py:94-98,
+    :206-212; main.py:63 uses num_workers=0) is staged to the GPU, rendered by K1 and handed back as a CPU tensor
+    (renderers._HostStaging).  ``patch_renderer=False`` leaves ``renderers.LocalRenderer`` the reference's -- for a machine
+    without a GPU in the data process, or forked DataLoader workers (a forked child cannot use the GPU; this engine has
+    no CPU path) -- while the patched ``RenderingLoss`` / ``MixedLoss`` still take the fused kernel: they recognise the
+    reference's ``LocalRenderer`` object as the renderer the kernels replace (``losses.RenderingLoss.uses_fused_kernel``)."""
     import importlib
     mine = {"renderers": renderers, "losses": losses}
     replaced = {}

@@ -74,3 +74,71 @@ def test_short_form_reports_the_median_region():
     with open(os.path.join(ROOT, "bench.py")) as f:
         src = f.read()
     assert "n_regions = 1 if args.steps >= 256 else max(9, args.regions)" in src
+
+
+def _made_up_measurements(**over):
+    B, steps = 8, 20
+    regions = [0.00076, 0.00074, 0.00075, 0.00080, 0.00074, 0.00075, 0.00076, 0.00075, 0.00074]
+    import bench
+    med = bench.median_region_index(regions)
+    m = {"B": B, "H": 256, "S": 9, "world": 1, "n_batches": 6, "elapsed": regions[med], "job_elapsed": regions,
+         "median_region": med, "n_regions": 9, "kernel_ms": sorted([0.0381, 0.0379, 0.0385, 0.0380] * 8), "kernel_ms_avg": 0.038125,
+         "region_ms_per_launch": 0.0361, "main_ns": 0, "timed_fast": False, "clock_ghz": 2.2, "clock_note": "made up",
+         "cycle_leg_ms": 0.0390, "other_ms_per_step": 0.0310, "other_ms": [0.060, 0.061, 0.062], "other_steps": 80,
+         "leg_steps": 600, "leaf_ms_per_step": 0.0355, "engine_ms_per_step": 0.0356, "engine_plain_ms_per_step": 0.0400,
+         "copy": {"GBps": 6550.0, "ms_per_launch": 0.328}, "mean_loss": 0.5,
+         "per_rank": {"elapsed_s": [regions[med]], "cpus": ["0-63"], "pci_crosscheck": ["match"]}, "ranks_seen": 1,
+         "process_group": None, "host_path": "native C++ extension (csrc/host_ext.cpp)"}
+    m.update(over)
+    return m
+
+
+def _args(*argv):
+    import sys
+    import bench
+    saved, sys.argv = sys.argv, ["bench.py"] + list(argv)
+    try:
+        return bench.parse_args()
+    finally:
+        sys.argv = saved
+
+
+def test_line_assembly_one_clock_and_every_mode():
+    """bench.assemble_line on made-up measurements (no GPU): the contract's identities in the default mode, under
+    --timed-only (no follow-up leg ran: their figures are None, nothing raises) and for a --streams 2 timed region.
+    (Round 6: a name clash in this code cost a whole profile collection -- it had only ever run on a GPU box.)"""
+    import bench
+    alg = 144.0 * 256 * 256 * 8
+    out, copy_gbps = bench.assemble_line(_args("--steps", "20", "--warmup", "5"), _made_up_measurements())
+    json.loads(json.dumps(out))                                             # serialisable
+    r = out["roofline"]
+    assert out["steps"] == 20 and abs(out["value"] - 8 * 1e3 / out["ms_per_step"]) <= 1e-9 * out["value"]
+    assert out["value"] == out["value_through_autograd_engine"] and out["config"]["backward"] == "autograd engine"
+    assert abs(out["value_leaf_shortcut"] - 8 / 0.0355e-3) < 1e-6 and copy_gbps == 6550.0
+    # ONE clock: frac x peak x ms_per_step / bytes == 1, exactly the interval `value` is priced with
+    assert abs(r["frac"] * 8e12 * out["ms_per_step"] * 1e-3 / alg - 1.0) < 1e-12 and r["time_per_step_ms"] == out["ms_per_step"]
+    assert abs(r["frac_by_launch_events"] - alg / 0.0361e-3 / 8e12) < 1e-12 and r["time_per_launch_ms"] == 0.0361
+    assert abs(r["frac_of_measured_copy_peak"] - r["achieved"] / 6550.0) < 1e-12 and r["copy_peak_GBps_measured"] == 6550.0
+    assert abs(r["shader_cycles_per_launch"] - 0.0390e-3 * 2.2e9) < 1e-6
+    assert out["timed_regions"]["count"] == 9 and out["timed_regions"]["value"][out["timed_regions"]["median_index"]] == out["value"]
+    if r["traffic"] is not None:                                            # the replayed counters of THIS build of the library
+        assert alg <= r["traffic"] <= 1.05 * alg and 0.3 < r["valu_issue_frac"] < 1.0
+    # --timed-only: what the profiler passes run
+    quiet = _made_up_measurements(clock_ghz=None, clock_note="not measured (--timed-only)", cycle_leg_ms=None,
+                                  other_ms_per_step=None, other_ms=[], other_steps=0, leg_steps=0, leaf_ms_per_step=None,
+                                  engine_ms_per_step=None, engine_plain_ms_per_step=None, copy=None)
+    out, copy_gbps = bench.assemble_line(_args("--steps", "20", "--timed-only"), quiet)
+    json.loads(json.dumps(out))
+    assert copy_gbps is None and out["follow_up_legs"].startswith("skipped") and out["value_two_streams_overlapped"] is None
+    assert out["value_leaf_shortcut"] is None and out["roofline"]["shader_cycles_per_launch"] is None
+    assert abs(out["roofline"]["frac"] * 8e12 * out["ms_per_step"] * 1e-3 / alg - 1.0) < 1e-12
+    # a two-stream timed region: no single launch stream, so no event pair; the one clock still holds
+    two = _made_up_measurements(main_ns=2, region_ms_per_launch=None)
+    out, _ = bench.assemble_line(_args("--steps", "20", "--streams", "2"), two)
+    json.loads(json.dumps(out))
+    assert out["roofline"]["time_per_launch_ms"] is None and out["config"]["streams_per_gpu"] == 2
+    assert abs(out["roofline"]["frac"] * 8e12 * out["ms_per_step"] * 1e-3 / alg - 1.0) < 1e-12
+    # --backward leaf: the timed region IS the leaf shortcut
+    leaf = _made_up_measurements(timed_fast=True)
+    out, _ = bench.assemble_line(_args("--steps", "20", "--backward", "leaf"), leaf)
+    assert out["value_leaf_shortcut"] == out["value"] and abs(out["value_through_autograd_engine"] - 8 / 0.0356e-3) < 1e-6
