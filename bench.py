@@ -16,9 +16,9 @@ elapsed time and two small reporting reductions.
 ONE CLOCK for the headline (round 6): `value`, `ms_per_step` and `roofline.achieved / frac` all come from the same
 interval -- the wall time of the (median) timed region, MAX over ranks.  `value` is the TRAINING-LOOP figure: every step on
 one stream, ``loss.backward()`` through PyTorch's autograd engine, which is what a network output gets (one kernel launch
-per step: the engine is handed the cached device-resident 1.0, the node skips its scale launch).  Untimed follow-up legs
-of the same process report, beside it: the engine-free accumulate a LEAF input resolves to (`value_leaf_shortcut`), the
-three-launch form of rounds 1-4, independent steps alternating on two streams, the shader clock under the loop (cycles per
+per step: the engine, entered from the extension, is handed the cached device-resident 1.0 and the node skips its scale
+launch).  Untimed follow-up legs of the same process report, beside it: the three-launch form of rounds 1-4 (the engine's
+own ones-fill kernel and the node's scale launch), independent steps alternating on two streams, the shader clock under the loop (cycles per
 launch), the copy bandwidth of this box (`copy_peak_GBps_measured`, svbrdf_debug_copy on 1 GiB) and the stand-alone
 rates of the HBM-bound kernels against it.
 
@@ -108,11 +108,6 @@ def parse_args():
                          "prints a diagnosis (backend, devices, HSA_ENABLE_IPC_MODE_LEGACY, ...) and exits with code 3.  The "
                          "limit covers the rendezvous: raise it for multi-node jobs and cold starts in which ranks page in their "
                          "images at very different speeds")
-    ap.add_argument("--backward", default="engine", choices=("engine", "leaf"),
-                    help="how the timed region's loss.backward() runs: 'engine' (default) = through PyTorch's autograd engine, "
-                         "what a network output gets -- the training-loop figure; 'leaf' = the engine-free accumulate a plain "
-                         "backward() on a LEAF input resolves to on torch 2.10 (rounds 1-5's `value`); the other one is "
-                         "reported from an untimed follow-up leg either way")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget of the main leg (the probes, the "
                     "one-thread figure and the C port add ~9 s)")
     ap.add_argument("--engine-threads", action="store_true",
@@ -214,8 +209,8 @@ def median_region_index(job_elapsed):
 
 MEASURED_KEYS = (
     "B", "H", "S", "world", "n_batches", "elapsed", "job_elapsed", "median_region", "n_regions", "kernel_ms",
-    "kernel_ms_avg", "region_ms_per_launch", "main_ns", "timed_fast", "clock_ghz", "clock_note", "cycle_leg_ms",
-    "other_ms_per_step", "other_ms", "other_steps", "leg_steps", "leaf_ms_per_step", "engine_ms_per_step",
+    "kernel_ms_avg", "region_ms_per_launch", "main_ns", "clock_ghz", "clock_note", "cycle_leg_ms",
+    "other_ms_per_step", "other_ms", "other_steps", "leg_steps", "engine_ms_per_step",
     "engine_plain_ms_per_step", "copy", "mean_loss", "per_rank", "ranks_seen", "process_group", "host_path",
 )
 
@@ -228,8 +223,8 @@ def assemble_line(args, m):
     from svbrdf_estimation_amd import _native
     (
         B, H, S, world, n_batches, elapsed, job_elapsed, median_region, n_regions, kernel_ms, kernel_ms_avg,
-        region_ms_per_launch, main_ns, timed_fast, clock_ghz, clock_note, cycle_leg_ms, other_ms_per_step, other_ms,
-        other_steps, leg_steps, leaf_ms_per_step, engine_ms_per_step, engine_plain_ms_per_step, copy, mean_loss,
+        region_ms_per_launch, main_ns, clock_ghz, clock_note, cycle_leg_ms, other_ms_per_step, other_ms,
+        other_steps, leg_steps, engine_ms_per_step, engine_plain_ms_per_step, copy, mean_loss,
         per_rank, ranks_seen, process_group, host_path
     ) = (m[k] for k in MEASURED_KEYS)
     patches = world * B * args.steps
@@ -283,18 +278,14 @@ def assemble_line(args, m):
                       "clock_GHz_under_load": clock_ghz, "clock_source": clock_note}
     working_set = n_batches * (2 * 12 + 12) * H * H * B * 4
     timed_is = ("loss.backward() through PyTorch's autograd engine (what a network output gets: the training-loop figure; one "
-                "kernel launch per step)" if not timed_fast else
-                "the engine-free accumulate a plain loss.backward() on a LEAF input resolves to (--backward leaf)")
-    value_leaf = rate(leaf_ms_per_step, world)
-    value_engine = patches / elapsed if not timed_fast else rate(engine_ms_per_step, world)
+                "kernel launch per step)")
     out = {
         "metric": "rendered 256x256 patches/sec (fwd+bwd rendering loss)",
         "value": patches / elapsed, "unit": "patches/s", "n_gpus": world,
         "per_gpu_value": patches / elapsed / world,
         "value_is": timed_is,
         # the same figure under its round-5 name (then a follow-up leg; since round 6 it IS the timed region)
-        "value_through_autograd_engine": value_engine,
-        "value_leaf_shortcut": value_leaf if not timed_fast else patches / elapsed,
+        "value_through_autograd_engine": patches / elapsed,
         "value_through_autograd_engine_with_fill_and_scale_launches": rate(engine_plain_ms_per_step, world),
         "valu_issue_frac": valu_issue["frac"] if valu_issue else None,      # what bounds K3 (also in roofline, with its inputs)
         "value_single_stream": rate(one["ms_per_step"], world),
@@ -311,12 +302,10 @@ def assemble_line(args, m):
         "value_note": (("`value` = the MEDIAN of %d consecutive timed regions of %d steps each (all listed in timed_regions); "
                         % (n_regions, args.steps)) if n_regions > 1 else "") +
                       "`value` = patches / wall time of the timed region: every step on %s, %s.  roofline.achieved and "
-                      "roofline.frac are priced with the same interval (ms_per_step).  Untimed follow-up legs of the same "
-                      "process: value_leaf_shortcut = %s; value_two_streams_overlapped = independent steps alternating on "
-                      "two streams (a bench-loop property, not a training loop's)"
-                      % ("ONE stream" if main_ns == 0 else "%d streams" % main_ns, timed_is,
-                         "the engine-free accumulate of a LEAF input (rounds 1-5's `value`)" if not timed_fast else
-                         "this region itself (see value_through_autograd_engine for the engine)"),
+                      "roofline.frac are priced with the same interval (ms_per_step).  Untimed follow-up leg of the same "
+                      "process: value_two_streams_overlapped = independent steps alternating on two streams (a bench-loop "
+                      "property, not a training loop's)"
+                      % ("ONE stream" if main_ns == 0 else "%d streams" % main_ns, timed_is),
         "ranks_seen": ranks_seen,       # summed by the bring-up all-reduce itself, not read from the environment
         "process_group": process_group,
         "per_rank": per_rank,
@@ -333,7 +322,7 @@ def assemble_line(args, m):
                    "global_batch": world * B, "H": H, "W": H, "scenes": S,
                    "parallelism": "batch-sharded x%d, no data-path collective" % world,
                    "streams_per_gpu": n_streams,
-                   "backward": "autograd engine" if not timed_fast else "leaf shortcut",
+                   "backward": "autograd engine",
                    "distinct_batches": n_batches,
                    "working_set_MiB": working_set / 2.0 ** 20,
                    "working_set_note": "input + target + gradient of every batch visited round-robin; the Infinity "
@@ -388,19 +377,16 @@ def assemble_line(args, m):
                                            "batches, so one step's kernel fills the ramp and tail of the other's.  A "
                                            "bench-loop property: not what one training loop gets"},
         "backward_modes": {
-            "timed_region": "engine" if not timed_fast else "leaf shortcut",
+            "timed_region": "engine_one_launch_per_step",
             "engine_one_launch_per_step": {"patches_per_s": rate(engine_ms_per_step), "ms_per_step": engine_ms_per_step},
             "engine_with_fill_and_scale_launches": {"patches_per_s": rate(engine_plain_ms_per_step),
                                                     "ms_per_step": engine_plain_ms_per_step},
-            "leaf_shortcut": {"patches_per_s": rate(leaf_ms_per_step), "ms_per_step": leaf_ms_per_step}
-                             if leaf_ms_per_step else ("not run" if args.timed_only else "not available on this torch version"),
             "steps_each": leg_steps,
-            "note": "per GPU, untimed follow-up legs on one stream, HIP events around each.  engine_one_launch_per_step: the "
-                    "engine is handed the extension's cached device-resident 1.0 and the node, recognising it by address and "
-                    "version, skips its scale launch (the timed region's mode by default); ..._with_fill_and_scale_launches: "
-                    "the engine's own ones-fill kernel and the node's no-op scale launch, as in rounds 1-4 (three kernels); "
-                    "leaf_shortcut: input.grad (+)= the buffer the kernel wrote, no engine (a LEAF input only: the notebooks' "
-                    "direct map optimisation, rounds 1-5's bench loop)"},
+            "note": "per GPU, untimed follow-up legs on one stream, HIP events around each.  engine_one_launch_per_step (the timed "
+                    "region's mode, once more): the engine, entered from the extension, is handed the cached device-resident 1.0 "
+                    "and the node, recognising it by address and version, skips its scale launch; "
+                    "..._with_fill_and_scale_launches: the engine's own ones-fill kernel and the node's no-op scale launch, as "
+                    "in rounds 1-4 (three kernels).  The engine-free leaf shortcut of rounds 2-5 is gone (no faster any more)"},
         "loss": mean_loss,
         "host_path": host_path,
         "autograd_engine": "multithreaded" if args.engine_threads else "calling thread",
@@ -592,10 +578,8 @@ def main():
     if quiet is not None:
         quiet(False)
     # `value` is the training-loop figure: loss.backward() through PyTorch's autograd engine (what a network output gets; one
-    # kernel launch per step).  The engine-free accumulate a LEAF input resolves to is timed in a follow-up leg
-    # (value_leaf_shortcut); --backward leaf makes it the timed region instead (rounds 1-5's `value`).
-    shortcut_available = bool(losses._FAST_BACKWARD)
-    losses._FAST_BACKWARD = shortcut_available and args.backward == "leaf"
+    # kernel launch per step: losses._FusedLossTensor).  (Rounds 1-5 timed an engine-free shortcut for leaf inputs; removed in
+    # round 6 -- the engine entered from the extension is as fast.)
     losses._UNIT_GRADIENT = True
     torch.cuda.synchronize(dev)               # inputs were produced on the default stream
     t_settle = time.perf_counter()
@@ -688,10 +672,9 @@ def main():
     # defaults of everything the follow-up legs produce (--timed-only skips them: the profiler passes, whose per-kernel average
     # should be the timed loop's launches and nothing else)
     main_ns = ns
-    timed_fast = bool(losses._FAST_BACKWARD)
     clock_ghz, clock_note, cycle_leg_ms = None, "not measured (--timed-only)", None
     other_ms_per_step, other_ms, other_steps, leg_steps = None, [], 0, 0
-    leaf_ms_per_step = engine_ms_per_step = engine_plain_ms_per_step = None
+    engine_ms_per_step = engine_plain_ms_per_step = None
     copy = None
     if not args.timed_only:
         # ---- untimed follow-up phases (same process, same tensors): the shader clock under this load, and the OTHER way of
@@ -764,15 +747,14 @@ def main():
             torch.cuda.set_stream(torch.cuda.default_stream(dev))
         ns = main_ns
         other_ms = sorted(p[0].elapsed_time(p[1]) for p in ev_other if p is not None)
-        # two more untimed legs, one stream: the OTHER way loss.backward() can run (the timed region took the engine with the unit
-        # gradient: one launch per step) -- the engine-free accumulate a LEAF input gets (losses._FusedLossTensor; torch 2.10 only),
-        # and the engine with its own ones-fill kernel and the node's no-op scale launch (rounds 1-4: three kernels per step).
+        # two more untimed legs, one stream, HIP events around each: the timed region's own mode once more (the engine with the
+        # unit gradient: one launch per step), and the engine with its own ones-fill kernel and the node's no-op scale launch
+        # (rounds 1-4: three kernels per step)
         saved_ns, ns = ns, 0
-        timed_fast = bool(losses._FAST_BACKWARD)
         leg_steps = max(600, other_steps)
 
-        def backward_mode_leg(fast, unit):
-            losses._FAST_BACKWARD, losses._UNIT_GRADIENT = fast, unit
+        def backward_mode_leg(unit):
+            losses._UNIT_GRADIENT = unit
             t_settle = time.perf_counter()
             while time.perf_counter() - t_settle < 20e-3:       # past the clock sag that follows the synchronize above (section 4.4)
                 for _ in range(32):
@@ -784,10 +766,9 @@ def main():
             e1.record(torch.cuda.current_stream(dev))
             torch.cuda.synchronize(dev)
             return e0.elapsed_time(e1) / leg_steps
-        leaf_ms_per_step = backward_mode_leg(True, True) if shortcut_available else None
-        engine_ms_per_step = backward_mode_leg(False, True)
-        engine_plain_ms_per_step = backward_mode_leg(False, False)
-        losses._FAST_BACKWARD, losses._UNIT_GRADIENT, ns = timed_fast, True, saved_ns
+        engine_ms_per_step = backward_mode_leg(True)
+        engine_plain_ms_per_step = backward_mode_leg(False)
+        losses._UNIT_GRADIENT, ns = True, saved_ns
 
         # the copy bandwidth of this box, measured in this run (rank 0's GPU; untimed leg)
         copy = None
@@ -801,9 +782,9 @@ def main():
         out, copy_gbps = assemble_line(args, {
             "B": B, "H": H, "S": S, "world": world, "n_batches": len(batches), "elapsed": elapsed, "job_elapsed": job_elapsed,
             "median_region": median_region, "n_regions": n_regions, "kernel_ms": kernel_ms, "kernel_ms_avg": kernel_ms_avg,
-            "region_ms_per_launch": region_ms_per_launch, "main_ns": main_ns, "timed_fast": timed_fast, "clock_ghz": clock_ghz,
+            "region_ms_per_launch": region_ms_per_launch, "main_ns": main_ns, "clock_ghz": clock_ghz,
             "clock_note": clock_note, "cycle_leg_ms": cycle_leg_ms, "other_ms_per_step": other_ms_per_step, "other_ms": other_ms,
-            "other_steps": other_steps, "leg_steps": leg_steps, "leaf_ms_per_step": leaf_ms_per_step,
+            "other_steps": other_steps, "leg_steps": leg_steps,
             "engine_ms_per_step": engine_ms_per_step, "engine_plain_ms_per_step": engine_plain_ms_per_step, "copy": copy,
             "mean_loss": mean_loss, "per_rank": per_rank, "ranks_seen": ranks_seen,
             "process_group": ("%s (%s), world size %d" % (args.backend, "RCCL" if nccl else "CPU transport, plumbing only",

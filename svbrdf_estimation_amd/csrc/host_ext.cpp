@@ -642,43 +642,6 @@ at::Tensor render_shared_scenes(const at::Tensor &maps_in, const at::Tensor &row
     return out;
 }
 
-// `loss.backward()` on a LEAF input without the engine.  The kernel has already produced d loss / d input for upstream
-// gradient 1, which is exactly what a plain loss.backward() asks for, so the engine's work for that call -- a fill
-// kernel for the implicit ones tensor, a graph task, this node's no-op scale launch, AccumulateGrad -- reduces to
-// "input.grad (+)= the buffer".  This does that and returns true when it is provably the same thing: `loss` is the
-// untouched output of this extension's node, only `input` needs a gradient, `input` is a leaf without tensor hooks,
-// post-accumulate hooks or hooks on its gradient accumulator, anomaly mode is off, and the caller's current stream
-// is the stream the kernel ran on (the engine would otherwise insert a stream sync).  Anything else returns false and
-// the caller falls back to torch.autograd.backward().  Measured: 19 -> 3 us of host time per step.
-bool fast_backward(const at::Tensor &loss, const at::Tensor &input, int64_t current_stream)
-{
-    const auto &fn = loss.grad_fn();
-    auto *node = dynamic_cast<FusedLossBackward *>(fn.get());
-    if (!node || node->done || !node->has_in || node->has_tg || !node->grad_in.defined()) return false;
-    if (reinterpret_cast<int64_t>(node->stream) != current_stream) return false;
-    if (!input.defined() || !input.is_leaf() || !input.requires_grad()) return false;
-    if (torch::autograd::AnomalyMode::is_enabled()) return false;
-    if (node->grad_in.sizes() != input.sizes() || node->grad_in.device() != input.device()) return false;
-    // the node's first edge must be this very leaf's accumulator
-    const auto acc = torch::autograd::impl::try_get_grad_accumulator(input);
-    if (!acc || node->next_edges().empty() || node->next_edge(0).function.get() != acc.get()) return false;
-    if (!acc->pre_hooks().empty() || !acc->post_hooks().empty() || !acc->tensor_pre_hooks().empty() ||
-        !acc->retains_grad_hooks().empty())
-        return false;
-    if (!torch::autograd::impl::hooks(input).empty() || torch::autograd::impl::post_acc_grad_hooks(input)) return false;
-    if (!node->pre_hooks().empty() || !node->post_hooks().empty() || !node->tensor_pre_hooks().empty()) return false;
-    node->done = true;
-    at::NoGradGuard no_grad;
-    at::Tensor &g = input.mutable_grad();
-    if (!g.defined()) {
-        g = std::move(node->grad_in);         // adopted, like AccumulateGrad does with a buffer it solely owns
-    } else {
-        g.add_(node->grad_in);
-        node->grad_in.reset();
-    }
-    return true;
-}
-
 // The upstream gradient of a plain `loss.backward()`: a 0-dim float32 1.0 on the loss's device, created once per device
 // (with the workspace, at the first forward) and never written by this extension; callers must not write it either -- if
 // one does, the version counter gives it away (State::ensure_unit_grad).  Handing it to torch.autograd.backward as the explicit gradient saves the engine's fill kernel, and
@@ -735,7 +698,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("fused_loss", &fused_loss);
     m.def("fused_loss_with_scenes", &fused_loss_with_scenes);
     m.def("sample_scene_table", &sample_scene_table);
-    m.def("fast_backward", &fast_backward);
     m.def("unit_gradient", &unit_gradient);
     m.def("engine_backward", &engine_backward, "loss.backward() through torch::autograd::backward with the unit gradient");
     m.def("render_shared_scenes", &render_shared_scenes);

@@ -118,37 +118,22 @@ def differentiable_loss_backward(input, target, scenes, eps, l1_weight, eps_l1, 
     return g_in, g_tg
 
 
-def _fast_backward_enabled():
-    """The engine-free ``loss.backward()`` of a leaf input (``_FusedLossTensor``) reads autograd internals that move
-    between torch releases (the leaf's gradient accumulator and its hook lists), so it is only taken on torch versions
-    it has been tested against; everywhere else ``loss.backward()`` is the autograd engine's.  SVBRDF_FAST_BACKWARD=0/1
-    overrides."""
-    import os
-    env = os.environ.get("SVBRDF_FAST_BACKWARD")
-    if env is not None:
-        return env not in ("0", "")
-    return ".".join(torch.__version__.split("+")[0].split(".")[:2]) in _FAST_BACKWARD_TESTED_TORCH
-
-
-_FAST_BACKWARD_TESTED_TORCH = ("2.10",)
-_FAST_BACKWARD = _fast_backward_enabled()
-
-
 class _FusedLossTensor(torch.Tensor):
     """The 0-dim loss the native host path returns when a gradient is wanted: an ordinary tensor, attached to the autograd
-    graph as usual, whose ``backward()`` makes a PLAIN call (no explicit gradient, no create_graph) cheaper in two ways.
+    graph as usual, whose PLAIN ``backward()`` (no explicit gradient, no create_graph) costs one kernel launch and no
+    Python in front of the engine:
 
-    * LEAF input (a material being optimised directly, the bench loop), nothing else needing a gradient: the extension is
-      asked whether the call is exactly "accumulate the gradient the kernel already produced into ``input.grad``" (no
-      retain graph, no ``inputs=``; leaf without hooks; same stream) and, if so, does just that instead of a trip through
-      the autograd engine (19 -> 3 us of host time).
-    * otherwise -- a network output, the training case -- the engine runs, but is handed the extension's cached
-      device-resident 1.0 as the explicit upstream gradient instead of filling a fresh ones tensor, and the loss's autograd
-      node, recognising that tensor by address and version, skips its (no-op) scale launch: the step stays ONE kernel launch
-      instead of three (fill, K3, scale).  Same values bit for bit: multiplying by 1.0 is what was skipped.  The engine is
-      entered from the extension (``torch::autograd::backward``, the public C++ call) rather than through
-      ``torch.autograd.backward``'s Python front end; a loss someone watches (a hook, ``retain_grad``) or an ``inputs=``
-      call takes the ordinary Python route.
+    * PyTorch's autograd engine runs, but is handed the extension's cached device-resident 1.0 as the explicit upstream
+      gradient instead of filling a fresh ones tensor, and the loss's autograd node, recognising that tensor by address and
+      version, skips its (no-op) scale launch: the step stays ONE kernel launch instead of three (fill, K3, scale).  Same
+      values bit for bit: multiplying by 1.0 is what was skipped.
+    * the engine is entered from the extension (``torch::autograd::backward``, the public C++ call) rather than through
+      ``torch.autograd.backward``'s Python front end (~6 us of interpreter time per step); a loss someone watches (a hook,
+      ``retain_grad``) or an ``inputs=`` call takes the ordinary Python route with the engine's own ones tensor.
+
+    (Rounds 2-5 also had an engine-FREE shortcut for leaf inputs that walked autograd internals -- the leaf's gradient
+    accumulator and hook lists -- behind a torch-version gate.  With the engine entered from C++ it bought nothing any more
+    (224.9 vs 224.7 k patches/s, profiles/HISTORY.md) and it was the fragile part of this file: removed in round 6.)
 
     Every other use -- an explicit gradient, ``create_graph=True``, a second ``backward()``, arithmetic on the loss (which
     yields a plain tensor), ``torch.autograd.grad`` -- goes through autograd unchanged."""
@@ -158,10 +143,7 @@ class _FusedLossTensor(torch.Tensor):
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         src = self.__dict__.pop("_svbrdf_src", None)
         if src is not None and gradient is None and not create_graph:
-            inner, leaf, ext = src
-            if leaf is not None and _FAST_BACKWARD and not retain_graph and inputs is None:
-                if ext.fast_backward(inner, leaf, _native._raw_stream(leaf.device)):
-                    return None
+            inner, ext = src
             # not when someone watches the loss's gradient (a hook, retain_grad): they get the engine's own fresh ones
             # tensor, theirs to edit; the node then sees an ordinary gradient and applies it
             if _UNIT_GRADIENT and self._backward_hooks is None and not self.retains_grad:
@@ -249,8 +231,7 @@ class RenderingLoss(nn.Module):
                                   float(l1_weight), float(eps_l1), _native._raw_stream(input.device), bool(head))
             if loss.requires_grad:
                 out = loss.as_subclass(_FusedLossTensor)       # see _FusedLossTensor: a plain backward() is made cheaper
-                leaf_only = input.is_leaf and input.requires_grad and not target.requires_grad
-                out.__dict__["_svbrdf_src"] = (loss, input if leaf_only else None, ext)
+                out.__dict__["_svbrdf_src"] = (loss, ext)
                 return out
             return loss
         table = self.sample_scene_table(input.shape[0])

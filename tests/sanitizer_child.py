@@ -60,7 +60,7 @@ def run_hostext():
     library that lacks a symbol), the scene sampler against the reference's per-item draw order and RNG state for every
     shape class (no random / no specular scenes, fewer and more than 16 normal draws per item: ATen's two code paths) and
     against the g5 fixture, the argument checks of the three entry points (the 288-row limit of a host scene table sits
-    BEHIND the device check and is reached on a GPU only, like the autograd nodes), fast_backward's refusals, the
+    BEHIND the device check and is reached on a GPU only, like the autograd nodes), engine_backward's / unit_gradient's refusals, the
     measurement-event and second-order-hook setters."""
     import numpy as np
     import torch
@@ -104,8 +104,7 @@ def run_hostext():
     n += raises(lambda: ext.bind(os.path.join(ROOT, "oracle", "_build", "libsvbrdf_oracle.so")), "does not export")
     n += raises(lambda: ext.bind("/nonexistent/libsvbrdf_hip.so"), "cannot load")
     ext.bind(_native.library_path())                        # and back to the real library
-    leaf = torch.zeros(3, requires_grad=True)
-    assert ext.fast_backward((leaf * 2).sum(), leaf, 0) is False and ext.fast_backward(torch.zeros(()), leaf, 0) is False
+    n += raises(lambda: ext.engine_backward(torch.zeros(()), False), "float32 device tensor")
     ext.set_timing_events(0, 0)
     ext.set_second_order_hooks(None, None)
     ext.set_second_order_hooks(_hostext._loss_second_order, _hostext._render_second_order)

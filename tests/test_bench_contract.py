@@ -83,9 +83,9 @@ def _made_up_measurements(**over):
     med = bench.median_region_index(regions)
     m = {"B": B, "H": 256, "S": 9, "world": 1, "n_batches": 6, "elapsed": regions[med], "job_elapsed": regions,
          "median_region": med, "n_regions": 9, "kernel_ms": sorted([0.0381, 0.0379, 0.0385, 0.0380] * 8), "kernel_ms_avg": 0.038125,
-         "region_ms_per_launch": 0.0361, "main_ns": 0, "timed_fast": False, "clock_ghz": 2.2, "clock_note": "made up",
+         "region_ms_per_launch": 0.0361, "main_ns": 0, "clock_ghz": 2.2, "clock_note": "made up",
          "cycle_leg_ms": 0.0390, "other_ms_per_step": 0.0310, "other_ms": [0.060, 0.061, 0.062], "other_steps": 80,
-         "leg_steps": 600, "leaf_ms_per_step": 0.0355, "engine_ms_per_step": 0.0356, "engine_plain_ms_per_step": 0.0400,
+         "leg_steps": 600, "engine_ms_per_step": 0.0356, "engine_plain_ms_per_step": 0.0400,
          "copy": {"GBps": 6550.0, "ms_per_launch": 0.328}, "mean_loss": 0.5,
          "per_rank": {"elapsed_s": [regions[med]], "cpus": ["0-63"], "pci_crosscheck": ["match"]}, "ranks_seen": 1,
          "process_group": None, "host_path": "native C++ extension (csrc/host_ext.cpp)"}
@@ -114,7 +114,8 @@ def test_line_assembly_one_clock_and_every_mode():
     r = out["roofline"]
     assert out["steps"] == 20 and abs(out["value"] - 8 * 1e3 / out["ms_per_step"]) <= 1e-9 * out["value"]
     assert out["value"] == out["value_through_autograd_engine"] and out["config"]["backward"] == "autograd engine"
-    assert abs(out["value_leaf_shortcut"] - 8 / 0.0355e-3) < 1e-6 and copy_gbps == 6550.0
+    assert abs(out["backward_modes"]["engine_with_fill_and_scale_launches"]["patches_per_s"] - 8 / 0.0400e-3) < 1e-6
+    assert copy_gbps == 6550.0 and "value_leaf_shortcut" not in out
     # ONE clock: frac x peak x ms_per_step / bytes == 1, exactly the interval `value` is priced with
     assert abs(r["frac"] * 8e12 * out["ms_per_step"] * 1e-3 / alg - 1.0) < 1e-12 and r["time_per_step_ms"] == out["ms_per_step"]
     assert abs(r["frac_by_launch_events"] - alg / 0.0361e-3 / 8e12) < 1e-12 and r["time_per_launch_ms"] == 0.0361
@@ -125,12 +126,13 @@ def test_line_assembly_one_clock_and_every_mode():
         assert alg <= r["traffic"] <= 1.05 * alg and 0.3 < r["valu_issue_frac"] < 1.0
     # --timed-only: what the profiler passes run
     quiet = _made_up_measurements(clock_ghz=None, clock_note="not measured (--timed-only)", cycle_leg_ms=None,
-                                  other_ms_per_step=None, other_ms=[], other_steps=0, leg_steps=0, leaf_ms_per_step=None,
+                                  other_ms_per_step=None, other_ms=[], other_steps=0, leg_steps=0,
                                   engine_ms_per_step=None, engine_plain_ms_per_step=None, copy=None)
     out, copy_gbps = bench.assemble_line(_args("--steps", "20", "--timed-only"), quiet)
     json.loads(json.dumps(out))
     assert copy_gbps is None and out["follow_up_legs"].startswith("skipped") and out["value_two_streams_overlapped"] is None
-    assert out["value_leaf_shortcut"] is None and out["roofline"]["shader_cycles_per_launch"] is None
+    assert out["backward_modes"]["engine_one_launch_per_step"]["patches_per_s"] is None
+    assert out["roofline"]["shader_cycles_per_launch"] is None
     assert abs(out["roofline"]["frac"] * 8e12 * out["ms_per_step"] * 1e-3 / alg - 1.0) < 1e-12
     # a two-stream timed region: no single launch stream, so no event pair; the one clock still holds
     two = _made_up_measurements(main_ns=2, region_ms_per_launch=None)
@@ -138,7 +140,3 @@ def test_line_assembly_one_clock_and_every_mode():
     json.loads(json.dumps(out))
     assert out["roofline"]["time_per_launch_ms"] is None and out["config"]["streams_per_gpu"] == 2
     assert abs(out["roofline"]["frac"] * 8e12 * out["ms_per_step"] * 1e-3 / alg - 1.0) < 1e-12
-    # --backward leaf: the timed region IS the leaf shortcut
-    leaf = _made_up_measurements(timed_fast=True)
-    out, _ = bench.assemble_line(_args("--steps", "20", "--backward", "leaf"), leaf)
-    assert out["value_leaf_shortcut"] == out["value"] and abs(out["value_through_autograd_engine"] - 8 / 0.0356e-3) < 1e-6
