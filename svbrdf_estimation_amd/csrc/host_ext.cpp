@@ -674,6 +674,109 @@ void engine_backward(const at::Tensor &loss, bool retain_graph)
     torch::autograd::backward({loss}, {g}, retain_graph, /*create_graph=*/false, /*inputs=*/{});
 }
 
+// ------------------------------------------------------------------------------------------
+// input-photo scenes (row f3): the draws of SvbrdfDataset.render_inputs (dataset.py:172-204) for B samples of n photos each,
+// sample after sample in the reference's call order -- synthesis.input_scene_table restated without ~14 small tensor ops
+// per sample (25 us of interpreter time each; a batch of 8 was host-bound at 0.2 ms per call).  Per sample:
+//   uniform_(-0.75, 0.75) x2                    light x, y of the fronto-parallel first photo (z = 2.197)
+//   [n > 1]  direction sampler, n-1 lights      r1 ~ U(0.001, 0.98) then r2 ~ U(0, 1) (utils.py:100-111), x 2.197
+//   [aug]    normal_(-2, 0.5) x1 -> exp         spread of the light power;  normal_(20, spread) x n -> abs
+//   [aug]    normal_(1, 0.03) x 3n -> abs       white balance;  uniform_(0.25, 2.75) x n   view distances
+//   uniform_(-0.25, 0.25) x2                    view x, y of the first photo
+//   [n > 1]  direction sampler, n-1 views       x the photo's view distance
+// Uniform draws and normal draws of fewer than 16 elements are taken straight from the default CPU generator the way ATen's
+// serial kernels take them (see Sampler::draw_uniform; uniform_(lo, hi) = fma(u, hi - lo, lo) with hi - lo formed in
+// float); 16 and more normals go through Tensor.normal_ (ATen switches to its vectorised fill there).  sqrt / cos / sin / exp
+// are ATen's.  tests/test_host_logic.py: tables AND generator state bit-identical to the per-sample Python functions.
+// ------------------------------------------------------------------------------------------
+namespace {
+void draw_uniform_range(at::CPUGeneratorImpl *gen, float *dst, int64_t n, float lo, float hi)
+{
+    const float width = hi - lo;
+    std::lock_guard<std::mutex> lock(gen->mutex_);
+    for (int64_t i = 0; i < n; ++i)
+        dst[i] = std::fmaf((float)(gen->random() & 0xFFFFFFu) * (1.0f / 16777216.0f), width, lo);
+}
+
+// Tensor(n).normal_(mean, std) into dst
+void draw_normal(at::CPUGeneratorImpl *gen, float *dst, int64_t n, double mean, double stdv)
+{
+    if (n >= 16) {
+        auto t = at::from_blob(dst, {n}, at::TensorOptions().dtype(at::kFloat));
+        t.normal_(mean, stdv);
+        return;
+    }
+    std::lock_guard<std::mutex> lock(gen->mutex_);
+    for (int64_t i = 0; i < n; ++i) {
+        at::normal_distribution<double> normal(mean, stdv);
+        dst[i] = static_cast<float>(normal(gen));
+    }
+}
+}  // namespace
+
+at::Tensor sample_input_scene_table(int64_t B, int64_t n, bool augment)
+{
+    TORCH_CHECK(B >= 1 && n >= 1, "sample_input_scene_table: B and the photo count must be positive");
+    auto *gen = at::get_generator_or_default<at::CPUGeneratorImpl>(c10::nullopt, at::detail::getDefaultCPUGenerator());
+    const auto f = at::TensorOptions().dtype(at::kFloat);
+    const int64_t d = n - 1;                                   // hemisphere directions per list
+    const float light_z = (float)2.197, fixed_view = (float)2.75, two_pi = (float)(2 * M_PI);
+    const float dir_lo = (float)(0.0 + 0.001), dir_hi = (float)(1.0 - 0.02);
+    auto table = at::empty({B, n, 9}, f);
+    // raw draws: [b][0 = lights, 1 = views][d]
+    auto r1 = at::empty({B, 2, std::max<int64_t>(d, 1)}, f), r2 = at::empty_like(r1);
+    std::vector<float> light_xy(2 * B), view_xy(2 * B), vdist(B * n, fixed_view), colour(B * n * 3, 30.0f), power(n), wb(3 * n);
+    auto spread = at::empty({1}, f);
+    float *p1 = r1.data_ptr<float>(), *p2 = r2.data_ptr<float>();
+    for (int64_t b = 0; b < B; ++b) {
+        draw_uniform_range(gen, &light_xy[2 * b], 2, -0.75f, 0.75f);
+        if (d > 0) {
+            draw_uniform_range(gen, p1 + (b * 2 + 0) * d, d, dir_lo, dir_hi);
+            draw_uniform_range(gen, p2 + (b * 2 + 0) * d, d, 0.0f, 1.0f);
+        }
+        if (augment) {
+            draw_normal(gen, spread.data_ptr<float>(), 1, -2.0, 0.5);
+            const float sd = at::exp(spread).data_ptr<float>()[0];          // torch.exp(...).numpy()[0]
+            draw_normal(gen, power.data(), n, 20.0, (double)sd);
+            draw_normal(gen, wb.data(), 3 * n, 1.0, 0.03);
+            for (int64_t i = 0; i < n; ++i)
+                for (int c = 0; c < 3; ++c) colour[(b * n + i) * 3 + c] = std::fabs(power[i]) * std::fabs(wb[3 * i + c]);
+            draw_uniform_range(gen, &vdist[b * n], n, 0.25f, 2.75f);
+        }
+        draw_uniform_range(gen, &view_xy[2 * b], 2, -0.25f, 0.25f);
+        if (d > 0) {
+            draw_uniform_range(gen, p1 + (b * 2 + 1) * d, d, dir_lo, dir_hi);
+            draw_uniform_range(gen, p2 + (b * 2 + 1) * d, d, 0.0f, 1.0f);
+        }
+    }
+    at::Tensor radius, cosv, sinv, z;
+    if (d > 0) {                                               // utils.generate_normalized_random_direction, whole batch at once
+        radius = at::sqrt(r1);
+        auto phi = r2 * two_pi;
+        cosv = at::cos(phi);
+        sinv = at::sin(phi);
+        z = at::sqrt(1.0f - radius * radius);
+    }
+    float *t = table.data_ptr<float>();
+    for (int64_t b = 0; b < B; ++b) {
+        float *row = t + b * n * 9;
+        row[0] = view_xy[2 * b]; row[1] = view_xy[2 * b + 1]; row[2] = vdist[b * n];
+        row[3] = light_xy[2 * b]; row[4] = light_xy[2 * b + 1]; row[5] = light_z;
+        for (int64_t i = 1; i < n; ++i) {
+            const int64_t l = (b * 2 + 0) * d + (i - 1), v = (b * 2 + 1) * d + (i - 1);
+            const float *rad = radius.data_ptr<float>(), *c = cosv.data_ptr<float>(), *sn = sinv.data_ptr<float>(),
+                        *zz = z.data_ptr<float>();
+            float *o = row + i * 9;
+            const float vd = vdist[b * n + i];
+            o[0] = (rad[v] * c[v]) * vd; o[1] = (rad[v] * sn[v]) * vd; o[2] = zz[v] * vd;
+            o[3] = (rad[l] * c[l]) * light_z; o[4] = (rad[l] * sn[l]) * light_z; o[5] = zz[l] * light_z;
+        }
+        for (int64_t i = 0; i < n; ++i)
+            for (int c = 0; c < 3; ++c) row[i * 9 + 6 + c] = colour[(b * n + i) * 3 + c];
+    }
+    return table;
+}
+
 // the sampler alone (host tensor) -- used by the bit-exactness tests
 at::Tensor sample_scene_table(int64_t batch, int64_t n_random, int64_t n_specular)
 {
@@ -698,6 +801,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("fused_loss", &fused_loss);
     m.def("fused_loss_with_scenes", &fused_loss_with_scenes);
     m.def("sample_scene_table", &sample_scene_table);
+    m.def("sample_input_scene_table", &sample_input_scene_table,
+          "[B,n,9] scenes of the input-photo synthesis, reference draw order (dataset.py:172-204)");
     m.def("unit_gradient", &unit_gradient);
     m.def("engine_backward", &engine_backward, "loss.backward() through torch::autograd::backward with the unit gradient");
     m.def("render_shared_scenes", &render_shared_scenes);

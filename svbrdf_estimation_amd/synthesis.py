@@ -20,7 +20,7 @@ import math
 import numpy as np
 import torch
 
-from . import _native, utils
+from . import _hostext, _native, utils
 
 MIN_EPS, MAX_EPS = 0.001, 0.02           # dataset.py:164-165
 FIXED_LIGHT_DISTANCE = 2.197             # dataset.py:166
@@ -71,16 +71,22 @@ def render_inputs(svbrdf, count, use_augmentation=True, noise="device", generato
     B, _, H, W = maps.shape
     if noise not in (None, "cpu", "device"):
         raise ValueError("noise must be None, 'cpu' or 'device'")
-    tables, fields = [], []
-    for _ in range(B):
-        tables.append(input_scene_table(count, use_augmentation))
-        if noise == "cpu":      # reference order: after a sample's scenes, per image: level, then the field
-            per_image = []
+    ext = _hostext.module()          # native sampler (csrc/host_ext.cpp): the same draws in the same order, bit for bit
+    if noise == "cpu":
+        tables, fields = [], []
+        for _ in range(B):
+            tables.append(ext.sample_input_scene_table(1, count, bool(use_augmentation))[0] if ext is not None
+                          else input_scene_table(count, use_augmentation))
+            per_image = []          # reference order: after a sample's scenes, per image: level, then the field
             for _i in range(count):
                 std = noise_std()
                 per_image.append(torch.zeros(1, 3, H, W).normal_(mean=0.0, std=std))
             fields.append(torch.cat(per_image, dim=0))
-    table = torch.stack(tables, dim=0)
+        table = torch.stack(tables, dim=0)
+    elif ext is not None:
+        table = ext.sample_input_scene_table(B, count, bool(use_augmentation))       # sample after sample, one call
+    else:
+        table = torch.stack([input_scene_table(count, use_augmentation) for _ in range(B)], dim=0)
     if noise == "cpu":
         # K1: [B,count,3,H,W]; the host table travels with the launch when it fits the argument block (pinned ring otherwise)
         out = _native.render_fwd(maps.detach(), table)

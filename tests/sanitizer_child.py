@@ -84,6 +84,17 @@ def run_hostext():
         got = ext.sample_scene_table(1, 3, 6)[0].numpy()
         np.testing.assert_allclose(got, g["seed_%d" % seed], rtol=1e-6, atol=2e-7)
         n += 1
+    from svbrdf_estimation_amd import synthesis                # the input-photo scene sampler (row f3), every shape class
+    for aug in (False, True):
+        for (B, cnt) in [(1, 1), (3, 2), (8, 5), (2, 6), (2, 16), (1, 20)]:
+            for seed in range(3):
+                torch.manual_seed(seed)
+                a = torch.stack([synthesis.input_scene_table(cnt, aug) for _ in range(B)])
+                sa = torch.get_rng_state()
+                torch.manual_seed(seed)
+                b = ext.sample_input_scene_table(B, cnt, aug)
+                assert torch.equal(a, b) and torch.equal(sa, torch.get_rng_state()), (aug, B, cnt, seed)
+                n += 1
     x = torch.zeros(2, 12, 8, 8)
 
     def raises(fn, text):
@@ -105,6 +116,7 @@ def run_hostext():
     n += raises(lambda: ext.bind("/nonexistent/libsvbrdf_hip.so"), "cannot load")
     ext.bind(_native.library_path())                        # and back to the real library
     n += raises(lambda: ext.engine_backward(torch.zeros(()), False), "float32 device tensor")
+    n += raises(lambda: ext.sample_input_scene_table(0, 1, True), "must be positive")
     ext.set_timing_events(0, 0)
     ext.set_second_order_hooks(None, None)
     ext.set_second_order_hooks(_hostext._loss_second_order, _hostext._render_second_order)

@@ -145,6 +145,34 @@ def test_cpp_sampler_equals_per_item_draws_and_rng_state():
             assert torch.equal(a, b) and torch.equal(sa, torch.get_rng_state()), (B, R, M, seed)
 
 
+def test_cpp_input_scene_sampler_equals_per_sample_draws_and_rng_state(golden):
+    """row f3: the native sampler of the input-photo scenes (csrc/host_ext.cpp sample_input_scene_table) against the
+    per-sample Python restatement of dataset.py:172-204 -- tables and generator state bit for bit, for every shape class
+    (one photo: no hemisphere draws; fewer and more than 16 normal draws per call: ATen's two code paths; with and without
+    augmentation) -- and against the scenes the reference itself produced (g10)."""
+    from svbrdf_estimation_amd import _hostext, synthesis
+    ext = _hostext.module()
+    assert ext is not None, "host extension not built"
+    for aug in (False, True):
+        for n in (1, 2, 4, 5, 6, 16, 20):              # 3n >= 16 from n = 6 (white balance), n >= 16 (light power)
+            for B in (1, 3, 8):
+                for seed in range(4):
+                    torch.manual_seed(seed)
+                    a = torch.stack([synthesis.input_scene_table(n, aug) for _ in range(B)])
+                    sa = torch.get_rng_state()
+                    torch.manual_seed(seed)
+                    b = ext.sample_input_scene_table(B, n, aug)
+                    assert torch.equal(a, b) and torch.equal(sa, torch.get_rng_state()), (aug, n, B, seed)
+    g = golden("g10_render_inputs.npz")
+    for aug in (0, 1):
+        for n in (1, 4):
+            k = "aug%d_n%d" % (aug, n)
+            torch.manual_seed(int(g[k + "__seed"]))
+            assert_same_as_fixture(ext.sample_input_scene_table(1, n, bool(aug))[0].numpy(), g[k + "__scenes"], k)
+    with pytest.raises(RuntimeError):
+        ext.sample_input_scene_table(0, 1, True)
+
+
 def test_rendering_loss_sampling_order_matches_reference(golden):
     from svbrdf_estimation_amd import losses, renderers
     g = golden("g5_scene_sampler.npz")
