@@ -662,8 +662,14 @@ def test_local_renderer_interface(dev, oracle, golden):
     wide = torch.zeros(3, 12, 16, 32, device=dev)
     wide[..., ::2] = _t(g["maps"], dev)
     assert torch.equal(R.render(sc2, wide[..., ::2]), out.detach())
+    # a HOST tensor (the reference dataloader's call, dataset.py:206-212) is rendered on the GPU and comes back a host tensor;
+    # what the engine cannot do for it still fails loudly: a gradient, a dtype it has no kernel for
+    host = torch.from_numpy(g["maps"])
+    assert R.render(sc, host).device.type == "cpu" and torch.equal(R.render(sc, host), out.detach().cpu())
     with pytest.raises(Exception):
-        R.render(sc, torch.zeros(12, 8, 8))                     # CPU tensor: fail loudly, no fallback
+        R.render(sc, host.clone().requires_grad_(True))
+    with pytest.raises(TypeError):
+        R.render(sc, torch.zeros(12, 8, 8, dtype=torch.float16))
     with pytest.raises(ValueError):
         R.render(sc, torch.zeros(12, 8, 4, device=dev))         # H != W
     with pytest.raises(TypeError):
@@ -676,7 +682,7 @@ def test_local_renderer_interface(dev, oracle, golden):
 def test_render_native_and_ctypes_host_paths_are_bitwise_identical(dev, golden):
     """LocalRenderer.render through csrc/host_ext.cpp (C++ autograd node) and through the Python/ctypes
     autograd.Function: same kernels, same bits, forward and backward; non-contiguous maps, a non-leaf input, repeated
-    backward under retain_graph, and the loud failure on CPU / fp16 tensors in both"""
+    backward under retain_graph, a host tensor staged through K1, and the loud failure on fp16 tensors in both"""
     from svbrdf_estimation_amd import _hostext, environment as env, renderers
     assert _hostext.module() is not None
     g = golden("g4_batched_one_scene.npz")
@@ -699,8 +705,9 @@ def test_render_native_and_ctypes_host_paths_are_bitwise_identical(dev, golden):
             wide = torch.zeros(3, 12, 16, 32, device=dev)
             wide[..., ::2] = _t(g["maps"], dev)
             res[name] = (out.detach(), first, x.grad.clone(), gw, R.render(sc, wide[..., ::2]))
+            assert torch.equal(R.render(sc, torch.from_numpy(g["maps"])), out.detach().cpu())       # host tensor: staged, K1
             with pytest.raises(Exception):
-                R.render(sc, torch.zeros(12, 8, 8))
+                R.render(sc, torch.zeros(12, 8, 8, dtype=torch.float16))
             with pytest.raises(Exception):
                 R.render(sc, torch.zeros(12, 8, 8, device=dev, dtype=torch.float16))
         finally:
