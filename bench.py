@@ -357,11 +357,10 @@ def assemble_line(args, m):
                      # event pairs around a SAMPLE of single launches (dispatch gap + kernel + event bubble each): evidence
                      # that a launch is what fills a step, never what the roofline is priced with
                      "kernel_launches_timed": len(kernel_ms),
-                     "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
-                     "kernel_ms_note": "pairs bracket every 32nd launch of the timed region (a region shorter than 256 steps: "
-                                       "every 16th of an untimed 512-step leg right after it); a pair spans the ~3 us dispatch "
-                                       "gap in front of the launch and its own end-of-pipe bubble, so it reads longer than "
-                                       "ms_per_step",
+                     "kernel_ms_avg": kernel_ms_avg, "kernel_ms_median": kernel_ms[len(kernel_ms) // 2] if kernel_ms else None,
+                     "kernel_ms_note": "pairs bracket every 16th launch of an untimed 512-step leg right after the timed region(s) (no "
+                                       "timed region carries timing events); a pair spans the ~3 us dispatch gap in front of "
+                                       "the launch and its own end-of-pipe bubble, so it reads longer than ms_per_step",
                      "valu_frac_of_fp32_peak": (FLOP_PER_PIXEL_SCENE * H * H * S * B / (ms_per_step * 1e-3))
                                                / (FP32_VALU_PEAK_TFLOPS * 1e12),
                      "valu_issue": valu_issue},
@@ -523,14 +522,12 @@ def main():
     loss_fn.specular_configuration_count = args.specular_scenes
     torch.manual_seed(distributed.rank_seed(313, rank))    # per-rank scene RNG
 
-    # HIP events around individual kernel launches on the launch stream, on every 32nd timed step (a timing event is an
-    # end-of-pipe timestamp: each bracketed launch costs its stream ~10 us of idle once the loop is GPU-bound, so the
-    # launches are sampled: 63 samples at the default 2000 steps).  A short timed region (the driver's --steps 20 is 0.8 ms)
-    # gets NO per-launch events -- two bubbles would be 2.5 % of it -- and the samples (32 of them) are taken in an untimed
-    # 512-step leg right after it instead.  The roofline is priced with the ONE event pair around the whole region either way.
-    sample_in_region = args.steps >= 256
-    n_sample_leg = args.steps if sample_in_region else 512        # short form: 32 samples (was 8 until round 4)
-    stride = 32 if sample_in_region else 16
+    # HIP events around individual kernel launches on the launch stream: evidence that one launch is what fills a step, never
+    # what anything is priced with.  A timing event is an end-of-pipe timestamp -- each bracketed launch costs its stream ~10 us
+    # of idle -- so NO timed region carries them (round 6; until then the 2000-step form sampled every 32nd of its own steps:
+    # 0.8 % of the region): every 16th launch of an untimed 512-step leg right after the timed region(s) is bracketed instead.
+    sample_in_region = False
+    n_sample_leg, stride = 512, 16
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           if i % stride == 0 else None for i in range(n_sample_leg)]
     state = {"i": -1}
@@ -656,7 +653,7 @@ def main():
                     "numa_node": [placement["numa_node"]], "cpu_binding": [placement["source"]],
                     "pci_crosscheck": [placement.get("pci_crosscheck")]}
 
-    if not sample_in_region:                # untimed: the per-launch event samples a short timed region does not carry
+    if not sample_in_region and not args.timed_only:     # untimed: the per-launch event samples no timed region carries
         _native.set_launch_hook(hook)
         for i in range(n_sample_leg):
             state["i"] = i
@@ -666,8 +663,8 @@ def main():
         _native.set_launch_hook(None)
         if ns:
             torch.cuda.set_stream(torch.cuda.default_stream(dev))
-    kernel_ms = sorted(p[0].elapsed_time(p[1]) for p in ev if p is not None)
-    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    kernel_ms = sorted(p[0].elapsed_time(p[1]) for p in ev if p is not None) if not args.timed_only else []
+    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms) if kernel_ms else None
 
     # defaults of everything the follow-up legs produce (--timed-only skips them: the profiler passes, whose per-kernel average
     # should be the timed loop's launches and nothing else)

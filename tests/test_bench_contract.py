@@ -53,6 +53,53 @@ def test_committed_bench_line_meets_the_contract(name):
     assert b["value"] / c["value"] > 1e3                                     # a reported baseline, not a target
 
 
+@pytest.mark.parametrize("name", ("r06_bench.json", "r06_bench_short.json", "r06_bench_short2.json"))
+def test_round6_bench_line_one_clock_copy_peak_cpu_fields(name):
+    """VERDICT round 5, items 2-4, on the committed round-6 lines: `value` is the training-loop figure and `roofline.frac` is
+    priced with value's own interval (frac x 8e12 x ms_per_step / bytes = 1.000); the copy bandwidth is measured in the run
+    and the HBM-bound kernels are priced against it; the CPU baseline states model and core count, every probed thread count
+    is a number, and the run is short."""
+    with open(os.path.join(ROOT, "profiles", name)) as f:
+        b = json.load(f)
+    assert b["metric"].startswith("rendered 256x256 patches/sec") and b["unit"] == "patches/s" and b["n_gpus"] == 1
+    assert b["dtype"] == "f32" and b["data"] == "synthetic" and "configs[1]" in b["config"]["workload"] and "model" not in b["config"]
+    assert b["vs_baseline"] is None and b["higher_is_better"] is True and b["scaling"] == "weak"
+    assert "autograd engine" in b["value_is"] and b["config"]["backward"] == "autograd engine"
+    assert b["value"] == b["value_through_autograd_engine"] == b["per_gpu_value"] and "value_leaf_shortcut" not in b
+    assert abs(b["value"] - 8 * 1e3 / b["ms_per_step"]) <= 1e-6 * b["value"]
+    r = b["roofline"]
+    alg = 144.0 * 256 * 256 * 8
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["algorithmic_bytes_per_launch"] == alg
+    assert abs(r["frac"] * 8e12 * b["ms_per_step"] * 1e-3 / alg - 1.0) < 1e-9          # ONE clock
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["time_per_step_ms"] == b["ms_per_step"]
+    assert r["time_per_launch_ms"] <= b["ms_per_step"] * 1.0001 and r["frac_by_launch_events"] >= r["frac"] * 0.9999
+    assert alg <= r["traffic"] <= 1.05 * alg and "kernel code sha256" in r["traffic_source"]
+    assert 70e3 < r["shader_cycles_per_launch"] < 90e3 and 0.3 < r["valu_issue_frac"] < 1.0
+    tr = b["timed_regions"]
+    assert tr["count"] == (9 if b["steps"] < 256 else 1) and abs(sorted(tr["value"])[tr["count"] // 2] - b["value"]) <= 1e-9 * b["value"]
+    # the copy bandwidth of the box, measured in this run
+    assert 5500.0 < b["copy_peak_GBps_measured"] < 8000.0 and r["copy_peak_GBps_measured"] == b["copy_peak_GBps_measured"]
+    assert abs(r["frac_of_measured_copy_peak"] - r["achieved"] / b["copy_peak_GBps_measured"]) < 1e-12
+    assert r["copy_peak"]["copied_correctly"] is True
+    modes = b["backward_modes"]
+    assert modes["engine_one_launch_per_step"]["patches_per_s"] >= modes["engine_with_fill_and_scale_launches"]["patches_per_s"]
+    if "secondary" in b:
+        for k in ("K1_render_fwd", "K2_render_bwd", "K4_mix_materials", "K1_render_inputs_noise_clamp"):
+            v = b["secondary"][k]
+            assert v["frac_of_hbm_peak"] >= 0.70 and abs(v["frac_of_measured_copy_peak"] - v["algorithmic_GBps"] / b["copy_peak_GBps_measured"]) < 1e-9
+        assert b["secondary"]["render_inputs_B8_views1"]["kernel_launches_per_call"] == 1.0
+        assert b["secondary"]["LocalRenderer_render_host_tensor"]["renders_per_s"] > 2000.0
+    c = b["cpu_baseline"]
+    if c is not None:
+        assert c["kind"] == "port" and c["unit"] == "patches/s" and c["value"] > 0 and 1 <= c["cores"] <= c["cpus"]
+        assert isinstance(c["cpu_model"], str) and c["cpu_model"] and "patches" in c["sample"]
+        assert all(isinstance(v, float) and v > 0 for v in c["probe_patches_per_s_by_threads"].values())
+        assert isinstance(c["largest_probe_patches_per_s"], float)
+        assert isinstance(c.get("all_cores_patches_per_s", 0.0), float)          # numeric or absent, never a sentence
+        assert b["value"] / c["value"] > 1e3
+        assert sum(b["wall_s"].values()) < 40.0                                  # the driver form is short
+
+
 def test_bench_source_emits_the_contract_keys():
     with open(os.path.join(ROOT, "bench.py")) as f:
         src = f.read()
@@ -127,12 +174,13 @@ def test_line_assembly_one_clock_and_every_mode():
     # --timed-only: what the profiler passes run
     quiet = _made_up_measurements(clock_ghz=None, clock_note="not measured (--timed-only)", cycle_leg_ms=None,
                                   other_ms_per_step=None, other_ms=[], other_steps=0, leg_steps=0,
-                                  engine_ms_per_step=None, engine_plain_ms_per_step=None, copy=None)
+                                  engine_ms_per_step=None, engine_plain_ms_per_step=None, copy=None, kernel_ms=[],
+                                  kernel_ms_avg=None)
     out, copy_gbps = bench.assemble_line(_args("--steps", "20", "--timed-only"), quiet)
     json.loads(json.dumps(out))
     assert copy_gbps is None and out["follow_up_legs"].startswith("skipped") and out["value_two_streams_overlapped"] is None
     assert out["backward_modes"]["engine_one_launch_per_step"]["patches_per_s"] is None
-    assert out["roofline"]["shader_cycles_per_launch"] is None
+    assert out["roofline"]["shader_cycles_per_launch"] is None and out["roofline"]["kernel_ms_median"] is None
     assert abs(out["roofline"]["frac"] * 8e12 * out["ms_per_step"] * 1e-3 / alg - 1.0) < 1e-12
     # a two-stream timed region: no single launch stream, so no event pair; the one clock still holds
     two = _made_up_measurements(main_ns=2, region_ms_per_launch=None)
