@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Host time of one bench step, by part: the step loop of bench.py on maps so small (32x32: the kernel takes ~3 us) that the
+loop is host-bound, so wall time per step IS host time per step.  Parts: `inp.grad = None`, the forward call (module call ->
+extension: sampler, launch, node), `loss.backward()` (extension -> engine -> node -> AccumulateGrad); then cProfile of the loop.
+    python tools/host_step_profile.py [size]"""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch                                                      # noqa: E402
+
+from bench import synthetic_maps                                  # noqa: E402
+from svbrdf_estimation_amd import losses, renderers               # noqa: E402
+
+
+def main():
+    H = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    dev = torch.device("cuda:0")
+    torch.set_num_threads(8)
+    torch.autograd.set_multithreading_enabled(False)
+    gen = torch.Generator().manual_seed(1)
+    B = 8
+    batches = [(synthetic_maps(gen, B, H).to(dev).requires_grad_(True), synthetic_maps(gen, B, H).to(dev)) for _ in range(6)]
+    fn = losses.RenderingLoss(renderers.LocalRenderer())
+    N = 3000
+
+    def loop(n, what):
+        for k in range(n):
+            inp, tgt = batches[k % 6]
+            if what >= 1:
+                inp.grad = None
+            if what >= 2:
+                loss = fn(inp, tgt)
+                if what >= 3:
+                    loss.backward()
+    for what in (3, 3, 0, 1, 2, 3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop(N, what)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print("%-32s host %.2f us per step (+ %.2f us drain)" % (
+            ["loop + batch pick", "+ inp.grad = None", "+ forward (fn(inp, tgt))", "+ loss.backward()"][what],
+            1e6 * (t1 - t0) / N, 1e6 * (t2 - t1) / N), flush=True)
+    for name, flag in (("engine entered from the extension", True), ("torch.autograd.backward front end", False)):
+        losses._ENGINE_FROM_NATIVE = flag
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop(N, 3)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        print("full step, %-36s host %.2f us per step" % (name, 1e6 * (t1 - t0) / N), flush=True)
+    losses._ENGINE_FROM_NATIVE = True
+    pr = cProfile.Profile()
+    pr.enable()
+    loop(N, 3)
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr, stream=sys.stdout)
+    st.sort_stats("tottime").print_stats(14)
+
+
+if __name__ == "__main__":
+    main()
