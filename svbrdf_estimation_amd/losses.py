@@ -150,7 +150,9 @@ class _FusedLossTensor(torch.Tensor):
                 if inputs is None and _ENGINE_FROM_NATIVE:
                     # the same engine run, entered through torch::autograd::backward from the extension (no Python
                     # argument processing in front of the engine: ~6 us of the ~20 us a step spends on the host)
-                    ext.engine_backward(self, bool(retain_graph))
+                    # (from `inner`, the extension's own tensor: `self` is an alias of it that nobody watches -- checked
+                    # above -- so its AliasBackward node would only be one more node for the engine to walk)
+                    ext.engine_backward(inner, bool(retain_graph))
                     return None
                 gradient = ext.unit_gradient(inner)
         return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs)
