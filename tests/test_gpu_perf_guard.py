@@ -23,9 +23,11 @@ Thresholds and where they come from (cycles = time per launch x clock under that
 five boxes of rounds 5 and 6, profiles/r05_perf_guard.json, profiles/r06_perf_guard.json; they agree within 1.5 %):
   K3 config 2 (B = 8, 256x256, 9 scenes, tied roughness)   <= 90,000 cycles per launch      measured 85.5-87.6 k
   K3 config 2, MixedLoss (the training loss)               <= 95,000                        measured 91.2-92.1 k
-  K3 config 2, untied roughness (three lobes)              <= 124,000                       measured 119.2-122.1 k
+  K3 config 2, untied roughness (three lobes)              <= 126,000                       measured 119.2-122.1 k
   K3 config-5 shape (B = 8, 512x512, 11 + 21 scenes)       <= 930,000                       measured 893.9-895.9 k
-        = today + 2-4 % (round 5 shipped + 7-8 %; the round-5 review asked for what five agreeing boxes support).  The
+        = the slowest box seen + 3 % (round 5 shipped + 7-8 %; the round-5 review asked for what five agreeing boxes
+        support and proposed 124 k for the untied shape from one box's 119.3 k -- two other boxes read 121.9 and 122.1 k, so
+        that bound would have been 1.5 % away from a healthy box).  The
         repeat that is kept is the one with the FEWEST CYCLES (clock and duration of the same repeat), every repeat is
         recorded in perf_guard.json.
         NOTE on cycles: the clock under this kernel is not one number -- it moves between 2.0 and 2.4 GHz within
@@ -65,7 +67,7 @@ HBM_PEAK = 8.0e12
 # ---- thresholds (see the module docstring) ------------------------------------------------------------------------
 K3_CONFIG2_MAX_CYCLES = 90_000
 K3_MIXED_MAX_CYCLES = 95_000
-K3_UNTIED_MAX_CYCLES = 124_000
+K3_UNTIED_MAX_CYCLES = 126_000
 K3_CONFIG5_MAX_CYCLES = 930_000
 HBM_KERNELS_MIN_FRAC = 0.72
 COPY_MIN_FRAC = 0.72
