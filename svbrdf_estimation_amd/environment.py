@@ -167,8 +167,12 @@ def _triple(v, what):
     return vals
 
 
+def scene_floats(scene):
+    """any object with .camera.pos, .light.pos, .light.color -> nine python floats (camera xyz | light xyz | rgb)"""
+    return _triple(scene.camera.pos, "camera.pos") + _triple(scene.light.pos, "light.pos") + _triple(scene.light.color, "light.color")
+
+
 def scene_to_row(scene):
     """any object with .camera.pos, .light.pos, .light.color (lists, ndarrays or tensors) -> host fp32 [9]
     (float32 rounding of the values as ``torch.Tensor(...)`` does it, renderers.py:79,91,98)"""
-    return torch.tensor(_triple(scene.camera.pos, "camera.pos") + _triple(scene.light.pos, "light.pos")
-                        + _triple(scene.light.color, "light.color"), dtype=torch.float32)
+    return torch.tensor(scene_floats(scene), dtype=torch.float32)

@@ -178,6 +178,12 @@ class LocalRenderer:
                              "renderers.py:75), got %s" % (tuple(svbrdf.shape),))
         # the scene's nine floats stay on the host and travel with the launch: one dispatch per call, no H2D copy
         # (the reference uploads camera, light and colour with three synchronous copies, renderers.py:79,91,98)
+        ext = _hostext.module() if maps.is_cuda else None
+        if ext is not None and maps.dtype == torch.float32 and maps.device.index == torch.cuda.current_device():
+            # native host path (csrc/host_ext.cpp): same two kernels through the same C ABI, C++ autograd node; the scene goes
+            # over as nine python floats (rounded to float32 there like torch.Tensor(...) rounds them)
+            out = ext.render_one_scene(maps, environment.scene_floats(scene), _native._raw_stream(maps.device))
+            return out.view(maps.shape[0], 3, maps.shape[-2], maps.shape[-1])
         row = environment.scene_to_row(scene).view(1, 9)           # one scene, shared by every map of the batch
         if not maps.is_cuda:
             if maps.requires_grad and torch.is_grad_enabled():
@@ -185,12 +191,7 @@ class LocalRenderer:
                     "LocalRenderer.render got a CPU tensor that requires grad: host tensors are rendered forward-only (the "
                     "dataloader's call, dataset.py:206-212); move the maps to the ROCm device to differentiate through render")
             return _HostStaging.render(maps, row)
-        ext = _hostext.module() if maps.is_cuda else None
-        if ext is not None and maps.dtype == torch.float32 and maps.device.index == torch.cuda.current_device():
-            # native host path (csrc/host_ext.cpp): same two kernels through the same C ABI, C++ autograd node
-            out = ext.render_shared_scenes(maps, row, _native._raw_stream(maps.device))
-        else:
-            out = _RenderFunction.apply(maps, row)                 # ctypes path; raises on non-ROCm tensors
+        out = _RenderFunction.apply(maps, row)                     # ctypes path; raises on non-ROCm tensors
         return out.view(maps.shape[0], 3, maps.shape[-2], maps.shape[-1])
 
     def render_many(self, scene_table, svbrdf):

@@ -832,6 +832,31 @@ def test_render_inputs_fused_noise_and_clamp_epilogue(dev):
                 z = (_np(noisy[b, s_])[inner] - clean[inner]) / float(levels[b, s_])
                 n = z.size
                 assert abs(z.mean()) < 4.0 / np.sqrt(n) and abs(z.var() - 1.0) < 4.0 * np.sqrt(2.0 / n), (H, b, s_, z.mean(), z.var())
+    # BASELINE shape (B = 8, 256x256, 5 photos per sample = configs[3]'s view count): the field does not depend on the vector
+    # width the launch picked (SVBRDF_K1_VEC forces the narrower kernels: same bits), clamp-only is bitwise clamp(K1), every
+    # image's residual is standard normal where no clamp touched it
+    maps = _t(synth.make_maps(970, 8, 256), dev)
+    torch.manual_seed(256)
+    table = torch.stack([synthesis.input_scene_table(5, True) for _ in range(8)])
+    levels = synthesis.noise_levels(40).view(8, 5)
+    plain = _native.render_fwd(maps, table)
+    assert torch.equal(_native.render_inputs(maps, table), plain.clamp(0.0, 1.0))
+    wide = _native.render_inputs(maps, table, levels, 77, 12)
+    try:
+        for vec in ("2", "1"):
+            os.environ["SVBRDF_K1_VEC"] = vec
+            assert torch.equal(_native.render_inputs(maps, table, levels, 77, 12), wide), vec
+    finally:
+        os.environ.pop("SVBRDF_K1_VEC", None)
+    clean, got = _np(plain), _np(wide)
+    for b in range(8):
+        for s_ in range(5):
+            inner = (clean[b, s_] > 0.2) & (clean[b, s_] < 0.8)
+            if inner.sum() < 2000:
+                continue
+            z = (got[b, s_][inner] - clean[b, s_][inner]) / float(levels[b, s_])
+            assert abs(z.mean()) < 4.0 / np.sqrt(z.size) and abs(z.var() - 1.0) < 4.0 * np.sqrt(2.0 / z.size), (b, s_)
+            assert abs((z ** 4).mean() - 3.0) < 0.25
     # NaN maps stay NaN through the clamp (torch.clamp's behaviour), like clamp(K1)
     bad = _t(synth.make_maps(950, 1, 16), dev)
     bad[0, 4, 3, 5] = float("nan")
