@@ -56,6 +56,27 @@ def main():
         torch.cuda.synchronize()
         print("full step, %-36s host %.2f us per step" % (name, 1e6 * (t1 - t0) / N), flush=True)
     losses._ENGINE_FROM_NATIVE = True
+    # the plugin interface's one-scene render call (SURVEY 8d's secondary metric), forward and forward + backward, 256x256
+    from svbrdf_estimation_amd import environment
+    R = renderers.LocalRenderer()
+    scene = environment.Scene(environment.Camera([0.1, -0.2, 2.0]), environment.Light([0.4, 0.3, 1.5], [30.0, 30.0, 30.0]))
+    m = synthetic_maps(gen, 1, 256)[0].to(dev)
+    x = m.clone().requires_grad_(True)
+    cot = torch.randn(1, 3, 256, 256, device=dev)
+
+    def fwd_bwd():
+        x.grad = None
+        R.render(scene, x).backward(cot)
+    for name, call in (("LocalRenderer.render, forward", lambda: R.render(scene, m)), ("LocalRenderer.render, forward + backward", fwd_bwd)):
+        for _ in range(300):
+            call()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            call()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        print("%-44s host %.2f us per call, wall %.2f" % (name, 1e6 * (t1 - t0) / 2000, 1e6 * (time.perf_counter() - t0) / 2000), flush=True)
     pr = cProfile.Profile()
     pr.enable()
     loop(N, 3)
