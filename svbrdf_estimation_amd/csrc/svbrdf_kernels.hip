@@ -569,8 +569,10 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 {
 #pragma unroll
     for (int round = 0; round < 10; ++round) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one full 32 x 32 -> 64 multiply per product (v_mad_u64_u32): integer multiplies are quarter rate, and a
+        // separate v_mul_hi_u32 + v_mul_lo_u32 pair would cost two of them
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;
