@@ -174,6 +174,8 @@ def cpu_baseline(args, inp, tgt, table):
     one, _, _ = _time_eager(1, inp, tgt, table, budget_s=2.0, max_patches=4)
     res = {"value": rate, "unit": "patches/s", "cores": best, "kind": "port",
            "cpu_model": _cpu_model(), "cpus": ncpu,
+           # patches/s and renders/s (a patch = S scenes x (input + target) renders, forward + backward)
+           "renders_per_s": rate * int(table.shape[1]) * 2,
            "probe_patches_per_s_by_threads": {str(c): probe[c] for c in cands},
            "largest_probe_threads": cands[-1], "largest_probe_patches_per_s": probe[cands[-1]],
            "sample": "%d patches of %dx%d, S=%d, fwd+bwd, eager PyTorch restatement (oracle/eager_torch.py), "
