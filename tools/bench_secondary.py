@@ -251,8 +251,8 @@ def secondary_kernels(dev, H, copy_gbps):
         out["render_inputs_B%d_views%d" % (Bs, views)] = {
             "photos_per_s": Bs * views / dt, "ms_per_call": 1e3 * dt,
             "kernel_launches_per_call": (_native.launch_count() - launches) / n,
-            "note": "scene draws on the host in the reference's order + ONE launch of K1 with the noise + clamp epilogue "
-                    "(svbrdf_render_inputs_host_scenes), whole batch; host-bound on the per-sample scene draws"}
+            "note": "scene draws in the extension (the reference's draws in the reference's order) + ONE launch of K1 with the "
+                    "noise + clamp epilogue (svbrdf_render_inputs_host_scenes), whole batch"}
     del a, b
     mixed = losses.MixedLoss(renderers.LocalRenderer())
     # BASELINE configs[3]: batch 16, mixed loss (the multi-view network's output has the same loss shapes); its 144 scene

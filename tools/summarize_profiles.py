@@ -156,7 +156,7 @@ if cases:
                "cases": cases}, open(os.path.join(P, "%s_kernel_cases.json" % tag), "w"), indent=1, sort_keys=True)
 for name in ("bench_short.json", "bench_short2.json", "train_rccl_world1.json", "train_2ranks_share_device.json",
              "selftest_rccl_world1.json", "selftest_8ranks_share_device.json", "bench_host_disturbed.json",
-             "bench_short_after_suite.json", "bench_b.json"):
+             "bench_short_after_suite.json"):
     src = os.path.join(G, "%s_%s" % (tag, name))
     if os.path.exists(src):
         js = [l for l in open(src) if l.startswith("{")]
