@@ -100,9 +100,11 @@ def parse_args():
     ap.add_argument("--plumbing-only", action="store_true",
                     help="multi-rank control flow only (rank launch, rendezvous, barrier, MAX over ranks, one JSON line "
                          "with ranks_seen) without touching a GPU: what the CPU test suite runs with --backend gloo")
-    ap.add_argument("--regions", type=int, default=9,
+    ap.add_argument("--regions", type=int, default=15,
                     help="short forms (--steps < 256): timed regions of --steps steps each, run back to back; `value` is the "
-                         "median region (at least 9; the 2000-step default form times one region)")
+                         "median region (at least 9, default 15: a 20-step region is 0.74 ms and a host hiccup of a shared box "
+                         "costs a whole one -- with N ranks the job's region time is the MAX over ranks, so one rank's hiccup "
+                         "spoils it; the median of 15 tolerates seven; the 2000-step default form times one region)")
     ap.add_argument("--bringup-timeout", type=float, default=60.0,
                     help="N > 1: seconds the rendezvous + communicator set-up + first all-reduce may take before the rank "
                          "prints a diagnosis (backend, devices, HSA_ENABLE_IPC_MODE_LEGACY, ...) and exits with code 3.  The "
@@ -592,7 +594,7 @@ def main():
     # ---- the timed region(s).  One region = EXACTLY --steps steps between barrier + synchronize on both sides, its time the
     # MAX over ranks.  The default form (2000 steps, 75 ms) times one.  A SHORT form (the driver's --steps 20 is 0.76 ms of
     # GPU time) times N_REGIONS such regions back to back and reports the MEDIAN region: a single 0.8 ms region swung by
-    # +-6 % between runs on one box in round 4 (197-224 k), SURVEY 8d asks for a median over >= 100 iterations, and nine
+    # +-6 % between runs on one box in round 4 (197-224 k), SURVEY 8d asks for a median over >= 100 iterations, and nine (since late round 6: fifteen)
     # regions of 20 steps are 180.  Every region is listed in the JSON line (`timed_regions`).
     n_regions = 1 if args.steps >= 256 else max(9, args.regions)
     local_elapsed, region_ms, lasts = [], [], []

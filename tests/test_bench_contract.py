@@ -76,7 +76,8 @@ def test_round6_bench_line_one_clock_copy_peak_cpu_fields(name):
     assert alg <= r["traffic"] <= 1.05 * alg and "kernel code sha256" in r["traffic_source"]
     assert 70e3 < r["shader_cycles_per_launch"] < 90e3 and 0.3 < r["valu_issue_frac"] < 1.0
     tr = b["timed_regions"]
-    assert tr["count"] == (9 if b["steps"] < 256 else 1) and abs(sorted(tr["value"])[tr["count"] // 2] - b["value"]) <= 1e-9 * b["value"]
+    assert (tr["count"] >= 9 if b["steps"] < 256 else tr["count"] == 1) and len(tr["value"]) == tr["count"]
+    assert abs(sorted(tr["value"])[tr["count"] // 2] - b["value"]) <= 1e-9 * b["value"]
     # the copy bandwidth of the box, measured in this run
     assert 5500.0 < b["copy_peak_GBps_measured"] < 8000.0 and r["copy_peak_GBps_measured"] == b["copy_peak_GBps_measured"]
     assert abs(r["frac_of_measured_copy_peak"] - r["achieved"] / b["copy_peak_GBps_measured"]) < 1e-12
