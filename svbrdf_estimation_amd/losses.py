@@ -147,7 +147,7 @@ class _FusedLossTensor(torch.Tensor):
             # not when someone watches the loss's gradient (a hook, retain_grad): they get the engine's own fresh ones
             # tensor, theirs to edit; the node then sees an ordinary gradient and applies it
             if _UNIT_GRADIENT and self._backward_hooks is None and not self.retains_grad:
-                if inputs is None and _ENGINE_FROM_NATIVE:
+                if inputs is None and _ENGINE_FROM_NATIVE and not _functorch_active():
                     # the same engine run, entered through torch::autograd::backward from the extension (no Python
                     # argument processing in front of the engine: ~6 us of the ~20 us a step spends on the host)
                     # (from `inner`, the extension's own tensor: `self` is an alias of it that nobody watches -- checked
@@ -158,6 +158,8 @@ class _FusedLossTensor(torch.Tensor):
         return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs)
 
 
+# torch.autograd.backward refuses to run inside a functorch transform (vmap / grad): leave that error to it
+_functorch_active = getattr(torch._C, "_are_functorch_transforms_active", lambda: False)
 _UNIT_GRADIENT = True       # tests switch it off to compare against the engine's own ones tensor
 _ENGINE_FROM_NATIVE = True  # ... and this one to compare against torch.Tensor.backward(loss, unit_gradient)
 
