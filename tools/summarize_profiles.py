@@ -168,4 +168,17 @@ for name in ("perf_guard.json", "clock_timeline.txt", "valu_rate.txt", "gputest.
     if os.path.exists(src):
         keep = [l for l in open(src) if "amdgpu.ids" not in l]
         open(os.path.join(P, "%s_%s" % (tag, name)), "w").writelines(keep)
+# the placement check under the name the round-5 review asked for: both timing builds in one file, with what they are
+parts = [os.path.join(P, "%s_k3_placement_%s.txt" % (tag, v)) for v in ("tim0", "tim")]
+if all(os.path.exists(x) for x in parts):
+    with open(os.path.join(P, "%s_k3_placement.txt" % tag), "w") as f:
+        f.write("tools/k3_placement.py on two -DSVBRDF_TIMING=1 builds of K3 (per-wave stamps; HW_ID / XCC_ID per workgroup), config 2,\n"
+                "maps from HBM, five launches each.  Question: does the dispatcher place a launch's workgroups BREADTH-FIRST over the\n"
+                "256 CUs, as the load stagger of the shipped kernel assumes (layer = linear workgroup index >> 8 = which of a CU's\n"
+                "workgroup slots)?  Per layer: entry stamps (us after the launch's first entry; taken before the stagger's sleep),\n"
+                "distinct CUs, most workgroups of the layer on one CU.  The timing build needs 92 VGPRs (no real gradient stores) and is\n"
+                "resident FIVE layers deep; the product kernel (128 VGPRs) four.  Exit code 0 = every launch breadth-first.\n\n")
+        for x, title in zip(parts, ("=== sleep OFF (-DSVBRDF_K3_STAGGER=0): what the review asked for ===\n",
+                                    "=== sleep ON (the shipped stagger; stamps are taken before it) ===\n")):
+            f.write(title + "".join(l for l in open(x) if "amdgpu.ids" not in l) + "\n")
 print("wrote", sorted(os.listdir(P)))
