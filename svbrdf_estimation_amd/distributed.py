@@ -325,8 +325,8 @@ def first_contact_selftest(device, nccl, share_device, fixture_path, timeout_s=6
                 sys.stderr.write("[selftest]   %d ranks sit on %d distinct GPUs (%s): check LOCAL_RANK -> device mapping and "
                                  "ROCR/HIP_VISIBLE_DEVICES\n" % (world, distinct, ids))
             sys.stderr.flush()
-        try:
-            dist.barrier()
+        try:        # every rank has printed what it knows before any of them goes (rank 0's stderr is the one that is read)
+            dist.barrier(**({"device_ids": [device.index]} if nccl else {}))
         finally:
             os._exit(BRINGUP_EXIT_CODE)
     return res
