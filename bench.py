@@ -413,6 +413,9 @@ def plumbing_only(args, rank, world, placement):
         dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     places = [placement]
+    selftest = None
+    if world > 1 and args.selftest:     # the collective part of the first-contact self-test, without a device (CPU suite)
+        selftest = distributed.first_contact_selftest(None, False, False, None, args.bringup_timeout)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         places = [None] * seen
@@ -423,7 +426,8 @@ def plumbing_only(args, rank, world, placement):
                           "elapsed_max_over_ranks_s": float(t.item()),
                           "per_rank": {"cpus": [p["cpus"] for p in places], "numa_node": [p["numa_node"] for p in places],
                                        "cpu_binding": [p["source"] for p in places]},
-                          "launch": "self-spawned" if os.environ.get("SVBRDF_SELF_SPAWNED") else "external launcher"}),
+                          "launch": "self-spawned" if os.environ.get("SVBRDF_SELF_SPAWNED") else "external launcher",
+                          "selftest": selftest}),
               flush=True)
     if world > 1:
         dist.destroy_process_group()

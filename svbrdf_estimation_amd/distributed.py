@@ -275,7 +275,9 @@ def fixture_parity(device, fixture_path):
 
 def first_contact_selftest(device, nccl, share_device, fixture_path, timeout_s=60.0):
     """-> dict for the JSON line (ranks_seen, distinct_devices, allreduce_GBps per rank, parity per rank, ok); exits the
-    process with BRINGUP_EXIT_CODE (diagnosis on stderr) when a check fails or the whole thing exceeds `timeout_s`."""
+    process with BRINGUP_EXIT_CODE (diagnosis on stderr) when a check fails or the whole thing exceeds `timeout_s`.
+    `device` None (bench.py --plumbing-only, the CPU suite): the collective part only -- gathers and all-reduce rates over
+    gloo -- with the device checks (a) and (c) reported as skipped."""
     import os
     import sys
     import torch.distributed as dist
@@ -288,13 +290,13 @@ def first_contact_selftest(device, nccl, share_device, fixture_path, timeout_s=6
         return out
     try:
         wd.phase = "selftest (a): all-gather of PCI bus ids"
-        ids = gather(pci_bus_id(device))
+        ids = gather(pci_bus_id(device) if device is not None else "no device (plumbing only), rank %d" % rank)
         wd.phase = "selftest (b): 8 MB all-reduce"
         small = allreduce_rate(8 << 20, device, nccl)
         wd.phase = "selftest (b): 320 MB all-reduce (the U-Net's fp32 gradients)"
         large = allreduce_rate(320 << 20, device, nccl, reps=3)
         wd.phase = "selftest (c): fused loss against the committed reference fixture"
-        parity = fixture_parity(device, fixture_path)
+        parity = fixture_parity(device, fixture_path) if device is not None else {"ok": True, "skipped": "no device (plumbing only)"}
         wd.phase = "selftest: gathering the ranks' results"
         every = gather({"allreduce_8MB": small, "allreduce_320MB": large, "parity": parity})
     except BaseException as e:
@@ -306,7 +308,7 @@ def first_contact_selftest(device, nccl, share_device, fixture_path, timeout_s=6
         os._exit(BRINGUP_EXIT_CODE)
     wd.cancel()
     distinct = len(set(ids))
-    want_distinct = 1 if share_device else world
+    want_distinct = 1 if (share_device and device is not None) else world
     res = {"ranks_seen": world, "pci_bus_ids": ids, "distinct_devices": distinct, "distinct_devices_expected": want_distinct,
            "allreduce_GBps": {"8MB": [r["allreduce_8MB"]["GBps"] for r in every],
                               "320MB": [r["allreduce_320MB"]["GBps"] for r in every]},

@@ -253,6 +253,23 @@ def test_bring_up_error_after_a_successful_init_leaves_no_group_behind_and_can_b
     assert "Timeout (0:00:03)!" in r.stderr
 
 
+def test_selftest_collective_part_world_of_two_on_cpu():
+    """`bench.py --gpus 2 --selftest --plumbing-only` (self-spawned, gloo, no GPU): the collective part of the first-contact
+    self-test -- the gathers, the 8 MB and 320 MB all-reduces with their rates, sums checked, the verdict -- with the
+    device checks reported as skipped.  (With devices it runs in the GPU suite: tests/test_gpu_multirank.py.)"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest", "--plumbing-only"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    (line,) = _json_lines(r.stdout)
+    st = line["selftest"]
+    assert line["ranks_seen"] == 2 and st["ok"] is True and st["ranks_seen"] == 2 and st["distinct_devices"] == 2
+    assert st["allreduce_sums_correct"] is True and st["transport"].startswith("gloo")
+    for size in ("8MB", "320MB"):
+        assert len(st["allreduce_GBps"][size]) == 2 and all(v > 0 for v in st["allreduce_GBps"][size])
+    assert all(p.get("skipped") for p in st["parity"])
+
+
 def test_bench_refuses_a_world_that_is_not_gpus():
     """a launcher environment whose WORLD_SIZE contradicts --gpus must be an error, not a silent 1-rank run"""
     import subprocess
