@@ -115,3 +115,37 @@ def test_install_then_the_reference_shaped_training_script_runs_on_the_fused_ker
     r = subprocess.run([sys.executable, "main.py"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "STANDIN-MAIN-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
     print(r.stdout.strip().splitlines()[-1])
+
+
+class _RenderingDataset:
+    """a dataset whose items render a HOST map with the patched renderer, like SvbrdfDataset.__getitem__ (dataset.py:94-98)"""
+
+    def __len__(self):
+        return 2
+
+    def __getitem__(self, i):
+        import torch
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import synth
+        from svbrdf_estimation_amd import environment as env, renderers
+        maps = torch.from_numpy(synth.make_maps(40 + i, 1, 16))
+        scene = env.Scene(env.Camera(torch.tensor([0.0, 0.1, 2.75])), env.Light(torch.tensor([0.2, 0.1, 2.197]), torch.tensor([30.0, 30.0, 30.0])))
+        return renderers.LocalRenderer().render(scene, maps)[0]
+
+
+def test_dataloader_workers_forked_after_gpu_init_are_refused_spawned_ones_render():
+    """INTEGRATION.md section 1, the table of what still raises: a FORKED DataLoader worker whose parent has initialised the
+    GPU runtime cannot use the GPU -- the renderer says so (and names the ways out) instead of crashing in the runtime;
+    num_workers=0 (the reference's main.py:63) renders in the main process; a SPAWNED worker has a runtime of its own and
+    renders."""
+    import torch
+    from svbrdf_estimation_amd import NativeLibraryError
+    assert torch.cuda.is_available()
+    torch.zeros(1, device="cuda:0")                                         # the parent has initialised the runtime
+    main_process = torch.stack(list(torch.utils.data.DataLoader(_RenderingDataset(), batch_size=None, num_workers=0)))
+    assert main_process.device.type == "cpu" and tuple(main_process.shape) == (2, 3, 16, 16)
+    with pytest.raises(NativeLibraryError, match="forked worker"):
+        list(torch.utils.data.DataLoader(_RenderingDataset(), batch_size=None, num_workers=1, multiprocessing_context="fork"))
+    spawned = torch.stack(list(torch.utils.data.DataLoader(_RenderingDataset(), batch_size=None, num_workers=1,
+                                                           multiprocessing_context="spawn", timeout=300)))
+    assert torch.equal(spawned, main_process)
