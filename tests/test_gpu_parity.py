@@ -895,6 +895,31 @@ def test_render_inputs_fused_noise_and_clamp_epilogue(dev):
     assert rc == -2 and b"SVBRDF_HOST_SCENES_MAX_ROWS" in lib.svbrdf_last_error()
 
 
+def test_render_inputs_noise_field_seeded_sweep_of_shapes_seeds_and_offsets(dev):
+    """the noise epilogue over a seeded sweep of odd shapes (W from 1 to 12: every vector width, planes that are not a
+    multiple of four elements), batch and photo counts, full-range 64-bit seeds and offsets: element by element the numpy
+    restatement's field, for host and device tables alike"""
+    import philox_ref
+    from svbrdf_estimation_amd import _native, synthesis
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        W = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 12]))
+        B, S = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+        seed = int(rng.integers(0, 2 ** 63)) * 2 + int(rng.integers(0, 2))
+        offset = int(rng.integers(0, 2 ** 62)) * 4
+        maps = _t(synth.make_maps(3000 + case, B, W), dev)
+        torch.manual_seed(case)
+        table = torch.stack([synthesis.input_scene_table(S, bool(case % 2)) for _ in range(B)])
+        levels = (synthesis.noise_levels(B * S) * 6.0).view(B, S)
+        plain = _native.render_fwd(maps, table)
+        noisy = _native.render_inputs(maps, table, levels, seed, offset)
+        assert torch.equal(noisy, _native.render_inputs(maps, table.to(dev), levels.to(dev), seed, offset)), case
+        field = philox_ref.normal_field(seed, offset, plain.numel()).reshape(plain.shape)
+        want = np.clip(_np(plain).astype(np.float64) + levels.numpy().astype(np.float64)[:, :, None, None, None] * field, 0.0, 1.0)
+        err = np.abs(_np(noisy) - want)
+        assert err.max() <= 2e-7 + 3e-6 * float(levels.max()), (case, W, B, S, err.max())
+
+
 def test_render_of_a_host_tensor_is_the_device_call_and_serves_the_reference_dataloader(dev, golden):
     """the reference's SECOND caller of ``render`` is its dataloader, in the main process, with CPU
     tensors -- ``renderer.render(scene, svbrdf.unsqueeze(0))`` with tensor-valued positions and colour, CPU noise added to
