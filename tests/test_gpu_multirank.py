@@ -106,6 +106,33 @@ def test_bench_eight_self_spawned_ranks_as_the_scaling_run_starts_it():
     print("bench.py, eight ranks on one device: %.0f patches/s aggregate; slices %s" % (line["value"], pr["cpus"]))
 
 
+def test_bench_under_torch_distributed_run_with_the_kernels_in_it():
+    """the driver's N > 1 command, word for word -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps 20 --warmup 5` -- on the one GPU a box has (plus the
+    two flags that needs: gloo, every rank on cuda:0): the ranks come from the launcher's environment (no self-spawn),
+    LOCAL_RANK picks the device, the timed regions are the median of the job's (MAX over ranks), rank 0 alone prints"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
+                        "--warmup", "5", "--backend", "gloo", "--share-device", "--no-cpu-baseline", "--no-secondary"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.strip().startswith("{") and l.strip().endswith("}")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = lines[0]
+    assert line["launch"] == "external launcher" and line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert line["steps"] == 20 and line["warmup"] == 5 and line["timed_regions"]["count"] >= 9
+    assert line["config"]["global_batch"] == 16 and line["scaling"] == "weak" and line["value"] > 1e4
+    assert abs(line["value"] - 16 * 1e3 / line["ms_per_step"]) <= 1e-6 * line["value"]
+    alg = 144.0 * 256 * 256 * 8
+    assert abs(line["roofline"]["frac"] * 8e12 * line["ms_per_step"] * 1e-3 / alg - 1.0) < 1e-9      # per launch, one clock
+    assert line["per_rank"]["scene_seed"] == [313, 314] and len(line["per_rank"]["ms_per_step"]) == 2
+    print("bench.py under torch.distributed.run, two ranks on one device: %.0f patches/s aggregate" % line["value"])
+
+
 def _check_selftest_line(line, world, transport):
     assert line["selftest"] is True and line["ok"] is True and line["ranks_seen"] == world == line["n_gpus"]
     assert line["distinct_devices"] == line["distinct_devices_expected"] and len(line["pci_bus_ids"]) == world
