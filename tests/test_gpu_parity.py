@@ -822,7 +822,8 @@ def test_render_inputs_fused_noise_and_clamp_epilogue(dev):
         # v_log / v_sqrt / v_sin / v_cos are ~1 ulp of their results; the field enters scaled by sigma <= 0.05
         assert err.max() <= 2e-7 + 3e-6 * float(levels.max()), (H, err.max())
         assert noisy.min().item() >= 0.0 and noisy.max().item() <= 1.0
-        # statistics per image, on pixels no clamp touched: residual / sigma ~ N(0,1)
+        # statistics per image, on pixels no clamp touched: residual / sigma ~ N(0,1).  (4 sigma per image: this test makes
+        # ~150 such comparisons, which is 3 sigma family-wise; the element-by-element check above is the sharp one)
         for b in range(B):
             for s_ in range(S):
                 clean = _np(plain[b, s_])
