@@ -133,6 +133,24 @@ def test_bench_under_torch_distributed_run_with_the_kernels_in_it():
     print("bench.py under torch.distributed.run, two ranks on one device: %.0f patches/s aggregate" % line["value"])
 
 
+def test_bench_refuses_to_time_ranks_that_share_a_gpu_unannounced():
+    """a scaling number measured with two ranks on one device is not a scaling number: two ranks whose launcher maps both to
+    cuda:0 (LOCAL_RANK = 0 twice) without --share-device are found out before anything is timed -- the runtime's PCI
+    addresses, gathered, are not `world` distinct ones -- and the job exits with code 3 and the reason"""
+    from svbrdf_estimation_amd import launch
+    port = launch.free_port()
+    procs = []
+    for r in range(2):
+        env = _clean_env(RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                         MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                                       "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-secondary"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert [p.returncode for p in procs] == [3, 3], ([p.returncode for p in procs], outs[0][1][-1500:])
+    assert "2 ranks sit on 1 distinct GPUs" in outs[0][1] and not any(o[0].strip().startswith("{") for o in outs)
+
+
 def _check_selftest_line(line, world, transport):
     assert line["selftest"] is True and line["ok"] is True and line["ranks_seen"] == world == line["n_gpus"]
     assert line["distinct_devices"] == line["distinct_devices_expected"] and len(line["pci_bus_ids"]) == world
