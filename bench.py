@@ -488,19 +488,9 @@ def main():
         # never seen costs --bringup-timeout seconds and leaves a diagnosis on stderr (exit code 3), not the launcher's limit
         from svbrdf_estimation_amd import distributed as _d
         ranks_seen = _d.init_process_group_checked("nccl" if nccl else "gloo", dev, args.bringup_timeout)   # nccl = RCCL on ROCm
-        # every rank on a GPU of its own?  A scaling number measured with two ranks on one device is not a scaling number: each
-        # rank's PCI address as the runtime reports it, gathered, must be `world` distinct ones (unless --share-device says
-        # otherwise on purpose) -- checked before anything is timed, every rank reaching the same verdict from the same list
-        placement["runtime_pci"] = _d.pci_bus_id(dev)
-        pcis = [None] * dist.get_world_size()
-        dist.all_gather_object(pcis, placement["runtime_pci"])
-        if not args.share_device and len(set(pcis)) != dist.get_world_size():
-            if rank == 0:
-                sys.stderr.write("[bench] %d ranks sit on %d distinct GPUs (%s): LOCAL_RANK -> device mapping or ROCR/HIP_VISIBLE_DEVICES "
-                                 "is wrong (one rank per GPU; --share-device is for plumbing tests only)\n" % (len(pcis), len(set(pcis)), pcis))
-                sys.stderr.flush()
-            dist.destroy_process_group()
-            sys.exit(3)
+        # every rank on a GPU of its own?  A scaling number measured with two ranks on one device is not a scaling number:
+        # checked before anything is timed (exit code 3 with the reason)
+        placement["runtime_pci"] = _d.require_distinct_devices(dev, args.share_device, rank)[rank]
 
     def barrier():
         if nccl:

@@ -332,3 +332,22 @@ def first_contact_selftest(device, nccl, share_device, fixture_path, timeout_s=6
         finally:
             os._exit(BRINGUP_EXIT_CODE)
     return res
+
+
+def require_distinct_devices(device, share_device, rank):
+    """After the bring-up, before anything is timed or trained: every rank's GPU as the runtime reports it (PCI address),
+    gathered; `world` distinct ones or the job stops with exit code 3 and the reason -- two ranks on one device is a launcher
+    mistake (LOCAL_RANK -> device mapping, ROCR/HIP_VISIBLE_DEVICES) that would otherwise only show as a bad scaling number.
+    `share_device`: the plumbing tests' announced exception.  -> the list of addresses (rank order)."""
+    import sys
+    import torch.distributed as dist
+    pcis = [None] * dist.get_world_size()
+    dist.all_gather_object(pcis, pci_bus_id(device))
+    if not share_device and len(set(pcis)) != dist.get_world_size():
+        if rank == 0:
+            sys.stderr.write("[bring-up] %d ranks sit on %d distinct GPUs (%s): LOCAL_RANK -> device mapping or ROCR/HIP_VISIBLE_DEVICES "
+                             "is wrong (one rank per GPU; --share-device is for plumbing tests only)\n" % (len(pcis), len(set(pcis)), pcis))
+            sys.stderr.flush()
+        dist.destroy_process_group()
+        sys.exit(BRINGUP_EXIT_CODE)
+    return pcis

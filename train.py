@@ -188,6 +188,8 @@ def run(args):
         # rendezvous + communicator + one all-reduce under a watchdog (distributed.init_process_group_checked): exit code 3
         # and a diagnosis after --bringup-timeout seconds instead of the launcher's limit
         ranks_seen = distributed.init_process_group_checked(backend, dev if nccl else None, args.bringup_timeout)
+        if on_gpu:      # one rank per GPU, or the job stops here with the reason (--share-device: the plumbing tests' exception)
+            distributed.require_distinct_devices(dev, args.share_device, rank)
 
     def barrier():
         if nccl:
