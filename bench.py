@@ -433,224 +433,255 @@ def plumbing_only(args, rank, world, placement):
         dist.destroy_process_group()
 
 
-def main():
-    args = parse_args()
-    from svbrdf_estimation_amd import launch
-    if args.gpus > 1 and not launch.launched_as_rank():
-        # started as ONE plain process (`python bench.py --gpus N`): become the parent of N fresh rank processes.
-        # Nothing has initialised the GPU runtime in this process and nothing will (see launch.py).
-        os.environ["SVBRDF_SELF_SPAWNED"] = "1"
-        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
-    # this pool's host driver only supports dmabuf IPC: RCCL between rank processes needs it (read when the HSA runtime
-    # starts, i.e. at the first GPU call; the self-spawning parent sets it for its children too)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.backend is None:        # RCCL (nccl) unless every rank shares cuda:0, which RCCL refuses
-        args.backend = "gloo" if (args.share_device and world > 1) else "nccl"
-    elif args.backend == "nccl" and args.share_device and world > 1:
-        raise SystemExit("--share-device puts every rank on cuda:0, which RCCL does not support: use --backend gloo")
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (or let bench.py spawn them: run it "
-                         "without a rank environment)" % (args.gpus, world))
-    # first thing in a rank, before any GPU call: pin it to the CPUs next to its GPU (launch.py)
-    host_cpus = os.sched_getaffinity(0)         # the CPU baseline leg gets the whole host back
-    placement = launch.bind_rank_to_gpu_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), args.share_device)
-    if args.plumbing_only:
-        return plumbing_only(args, rank, world, placement)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    # The rank's own CPU work is tiny tensors (the scene sampler).  With torch's default intra-op pool -- one thread per
-    # core, 256 on the GPU box -- every host-side tensor op that does go parallel (generating the synthetic maps) leaves
-    # the pool's workers spinning for ~100-200 ms afterwards, and the launch path of the main thread ran 3-4x slow for that
-    # long (seen as a host-bound first leg after each new batch size; profiles/r03_dbg_mixed*.txt).  A small pool, and
-    # time-based settling before every timed leg.  (The CPU baseline sets its own thread counts.)
-    torch.set_num_threads(max(1, min(8, placement["n_cpus"])))
-    if not args.share_device and torch.cuda.device_count() <= local_rank:
-        raise SystemExit("local rank %d but only %d device(s) visible" % (local_rank, torch.cuda.device_count()))
-    if args.share_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # is this device the GPU the rank's CPUs were chosen for?  (PCI address from sysfs against the runtime's; undone if not)
-    placement = launch.crosscheck_placement(placement, local_rank, host_cpus)
-    dist = None
-    ranks_seen = 1
-    nccl = args.backend == "nccl"
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if world == 1:                          # --force-dist without a launcher: a rendezvous of one
-            os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-        # rendezvous + communicator + ONE one-element all-reduce under a watchdog: a bring-up problem on a node this code has
-        # never seen costs --bringup-timeout seconds and leaves a diagnosis on stderr (exit code 3), not the launcher's limit
-        from svbrdf_estimation_amd import distributed as _d
-        ranks_seen = _d.init_process_group_checked("nccl" if nccl else "gloo", dev, args.bringup_timeout)   # nccl = RCCL on ROCm
-        # every rank on a GPU of its own?  A scaling number measured with two ranks on one device is not a scaling number:
-        # checked before anything is timed (exit code 3 with the reason)
-        placement["runtime_pci"] = _d.require_distinct_devices(dev, args.share_device, rank)[rank]
+class Rank:
+    """what one rank process is and talks through: rank / world, its device, the process group (or None), its CPU placement"""
 
-    def barrier():
-        if nccl:
-            dist.barrier(device_ids=[local_rank])
+    def __init__(self, args):
+        from svbrdf_estimation_amd import launch
+        # this pool's host driver only supports dmabuf IPC: RCCL between rank processes needs it (read when the HSA runtime
+        # starts, i.e. at the first GPU call; the self-spawning parent sets it for its children too)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if args.backend is None:        # RCCL (nccl) unless every rank shares cuda:0, which RCCL refuses
+            args.backend = "gloo" if (args.share_device and self.world > 1) else "nccl"
+        elif args.backend == "nccl" and args.share_device and self.world > 1:
+            raise SystemExit("--share-device puts every rank on cuda:0, which RCCL does not support: use --backend gloo")
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (or let bench.py spawn them: run it "
+                             "without a rank environment)" % (args.gpus, self.world))
+        # first thing in a rank, before any GPU call: pin it to the CPUs next to its GPU (launch.py)
+        self.host_cpus = os.sched_getaffinity(0)         # the CPU baseline leg gets the whole host back
+        self.placement = launch.bind_rank_to_gpu_numa(self.local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", self.world)),
+                                                      args.share_device)
+        self.nccl = args.backend == "nccl"
+        self.dist, self.dev, self.ranks_seen = None, None, 1
+
+    def attach_device_and_group(self, args):
+        """the GPU and, for N > 1 (or --force-dist), the process group: bring-up under the watchdog, one rank per GPU"""
+        from svbrdf_estimation_amd import launch
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        # The rank's own CPU work is tiny tensors (the scene sampler).  With torch's default intra-op pool -- one thread per
+        # core, 256 on the GPU box -- every host-side tensor op that does go parallel (generating the synthetic maps) leaves
+        # the pool's workers spinning for ~100-200 ms afterwards, and the launch path of the main thread ran 3-4x slow for that
+        # long (seen as a host-bound first leg after each new batch size; profiles/r03_dbg_mixed*.txt).  A small pool, and
+        # time-based settling before every timed leg.  (The CPU baseline sets its own thread counts.)
+        torch.set_num_threads(max(1, min(8, self.placement["n_cpus"])))
+        if not args.share_device and torch.cuda.device_count() <= self.local_rank:
+            raise SystemExit("local rank %d but only %d device(s) visible" % (self.local_rank, torch.cuda.device_count()))
+        if args.share_device:
+            self.local_rank = 0
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        # is this device the GPU the rank's CPUs were chosen for?  (PCI address from sysfs against the runtime's; undone if not)
+        self.placement = launch.crosscheck_placement(self.placement, self.local_rank, self.host_cpus)
+        if self.world > 1 or args.force_dist:
+            import torch.distributed as dist
+            from svbrdf_estimation_amd import distributed
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.world == 1:                          # --force-dist without a launcher: a rendezvous of one
+                os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
+            # rendezvous + communicator + ONE one-element all-reduce under a watchdog: a bring-up problem on a node this code
+            # has never seen costs --bringup-timeout seconds and leaves a diagnosis on stderr (exit code 3), not the launcher's
+            # limit.  nccl = RCCL on ROCm
+            self.ranks_seen = distributed.init_process_group_checked("nccl" if self.nccl else "gloo", self.dev, args.bringup_timeout)
+            self.dist = dist
+            # every rank on a GPU of its own?  A scaling number measured with two ranks on one device is not a scaling
+            # number: checked before anything is timed (exit code 3 with the reason)
+            self.placement["runtime_pci"] = distributed.require_distinct_devices(self.dev, args.share_device, self.rank)[self.rank]
+
+    def barrier(self):
+        if self.dist is None:
+            return
+        if self.nccl:
+            self.dist.barrier(device_ids=[self.local_rank])
         else:
-            dist.barrier()
+            self.dist.barrier()
 
-    from svbrdf_estimation_amd import _native, distributed, losses, renderers
+    def gather(self, obj):
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(out, obj)
+        return out
 
-    if args.selftest:
-        # first contact with a multi-GPU node (tools/scale_first_contact.md): distinct devices, all-reduce rates, parity of
-        # the fused loss on every rank's device -- one JSON line, exit code 3 with a diagnosis when anything is off
-        if dist is None:
-            raise SystemExit("--selftest checks a process group: use --gpus N with N > 1, or --gpus 1 --force-dist")
-        res = distributed.first_contact_selftest(dev, nccl, args.share_device and not args.selftest_expect_distinct,
-                                                 os.path.join(ROOT, "tests", "golden", "g3_loss_7_s5.npz"), args.bringup_timeout)
-        places = [None] * dist.get_world_size()
-        dist.all_gather_object(places, placement)
-        if rank == 0:
-            res.update({"metric": "first-contact selftest (no throughput measured)", "selftest": True, "n_gpus": world,
-                        "ranks_seen": ranks_seen, "process_group": "%s, world size %d" % (args.backend, dist.get_world_size()),
-                        "launch": "self-spawned" if os.environ.get("SVBRDF_SELF_SPAWNED") else
-                                  ("external launcher" if world > 1 else "single process"),
-                        "per_rank": {"cpus": [p["cpus"] for p in places], "numa_node": [p["numa_node"] for p in places],
-                                     "pci_crosscheck": [p.get("pci_crosscheck") for p in places]}})
-            print(json.dumps(res), flush=True)
-        barrier()
-        dist.destroy_process_group()
-        return
+    def launch_word(self):
+        return "self-spawned" if os.environ.get("SVBRDF_SELF_SPAWNED") else ("external launcher" if self.world > 1 else "single process")
 
-    B, H, S = args.batch, args.size, args.random_scenes + args.specular_scenes
-    gen = torch.Generator().manual_seed(distributed.rank_seed(1234, rank))
-    inp_h, tgt_h = synthetic_maps(gen, B, H), synthetic_maps(gen, B, H)
-    batches = [(inp_h.to(dev).requires_grad_(True), tgt_h.to(dev))]
-    for _ in range(1, max(1, args.rotate)):
-        batches.append((synthetic_maps(gen, B, H).to(dev).requires_grad_(True), synthetic_maps(gen, B, H).to(dev)))
-    streams = [torch.cuda.Stream(dev) for _ in range(max(2, args.streams))]
-    loss_fn = losses.RenderingLoss(renderers.LocalRenderer())
-    loss_fn.random_configuration_count = args.random_scenes
-    loss_fn.specular_configuration_count = args.specular_scenes
-    torch.manual_seed(distributed.rank_seed(313, rank))    # per-rank scene RNG
 
-    # HIP events around individual kernel launches on the launch stream: evidence that one launch is what fills a step, never
-    # what anything is priced with.  A timing event is an end-of-pipe timestamp -- each bracketed launch costs its stream ~10 us
-    # of idle -- so NO timed region carries them (round 6; until then the 2000-step form sampled every 32nd of its own steps:
-    # 0.8 % of the region): every 16th launch of an untimed 512-step leg right after the timed region(s) is bracketed instead.
-    sample_in_region = False
-    n_sample_leg, stride = 512, 16
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          if i % stride == 0 else None for i in range(n_sample_leg)]
-    state = {"i": -1}
+def run_selftest(args, R):
+    """first contact with a multi-GPU node (tools/scale_first_contact.md): distinct devices, all-reduce rates, parity of the
+    fused loss on every rank's device -- one JSON line, exit code 3 with a diagnosis when anything is off"""
+    from svbrdf_estimation_amd import distributed
+    if R.dist is None:
+        raise SystemExit("--selftest checks a process group: use --gpus N with N > 1, or --gpus 1 --force-dist")
+    res = distributed.first_contact_selftest(R.dev, R.nccl, args.share_device and not args.selftest_expect_distinct,
+                                             os.path.join(ROOT, "tests", "golden", "g3_loss_7_s5.npz"), args.bringup_timeout)
+    places = R.gather(R.placement)
+    if R.rank == 0:
+        res.update({"metric": "first-contact selftest (no throughput measured)", "selftest": True, "n_gpus": R.world,
+                    "ranks_seen": R.ranks_seen, "process_group": "%s, world size %d" % (args.backend, R.dist.get_world_size()),
+                    "launch": R.launch_word(),
+                    "per_rank": {"cpus": [p["cpus"] for p in places], "numa_node": [p["numa_node"] for p in places],
+                                 "pci_crosscheck": [p.get("pci_crosscheck") for p in places]}})
+        print(json.dumps(res), flush=True)
+    R.barrier()
+    R.dist.destroy_process_group()
 
-    def hook(phase):
-        i = state["i"]
-        if 0 <= i < len(ev) and ev[i] is not None:
-            ev[i][0 if phase == "begin" else 1].record(torch.cuda.current_stream(dev))
-    _native.set_launch_hook(hook)             # ctypes host path
-    from svbrdf_estimation_amd import _hostext
-    ext = _hostext.module()                   # native host path: the pair is recorded inside the extension
-    raw_ev = []
-    if ext is not None:
-        for pair in ev:                       # create the raw hipEvent handles once
-            if pair is not None:
-                pair[0].record()
-                pair[1].record()
-        torch.cuda.synchronize(dev)
-        raw_ev = [(p[0].cuda_event, p[1].cuda_event) if p is not None else None for p in ev]
-        set_events = ext.set_timing_events
 
-    counter = {"k": 0}
-    nb, ns = len(batches), (args.streams if args.streams > 1 else 0)     # ns = 0: every step on the current stream
-    set_stream = torch.cuda.set_stream
+class StepLoop:
+    """The bench loop: six rotating (input, target) batches resident in HBM, the loss module, and `step()` = one pass of the
+    hot path -- ``inp.grad = None; loss = loss_fn(inp, tgt); loss.backward()`` -- issued on the current stream, or on stream
+    k mod `ns` when `ns` streams are in use.  Also owns the optional per-launch event pairs (`run_sampled`): a timing event
+    is an end-of-pipe timestamp -- each bracketed launch costs its stream ~10 us of idle -- so NO timed region carries them;
+    they bracket every `stride`-th launch of untimed legs only and are evidence that one launch fills a step, never what
+    anything is priced with."""
 
-    def step():
-        i = state["i"]
-        k = counter["k"]
-        counter["k"] = k + 1
-        if ns:
-            set_stream(streams[k % ns])       # the whole step (launch, backward) is issued on this stream
-        if raw_ev and 0 <= i < len(raw_ev) and raw_ev[i] is not None:
-            set_events(raw_ev[i][0], raw_ev[i][1])
-        inp, tgt = batches[k % nb]
+    def __init__(self, args, R):
+        from svbrdf_estimation_amd import _hostext, _native, distributed, losses, renderers
+        self.dev, self._native, self.losses = R.dev, _native, losses
+        B, H = args.batch, args.size
+        gen = torch.Generator().manual_seed(distributed.rank_seed(1234, R.rank))
+        self.inp_h, self.tgt_h = synthetic_maps(gen, B, H), synthetic_maps(gen, B, H)       # also the CPU baseline's inputs
+        self.batches = [(self.inp_h.to(R.dev).requires_grad_(True), self.tgt_h.to(R.dev))]
+        for _ in range(1, max(1, args.rotate)):
+            self.batches.append((synthetic_maps(gen, B, H).to(R.dev).requires_grad_(True), synthetic_maps(gen, B, H).to(R.dev)))
+        self.streams = [torch.cuda.Stream(R.dev) for _ in range(max(2, args.streams))]
+        self.loss_fn = losses.RenderingLoss(renderers.LocalRenderer())
+        self.loss_fn.random_configuration_count = args.random_scenes
+        self.loss_fn.specular_configuration_count = args.specular_scenes
+        torch.manual_seed(distributed.rank_seed(313, R.rank))    # per-rank scene RNG
+        self.ns = args.streams if args.streams > 1 else 0        # 0: every step on the current stream
+        self.k = 0
+        self.ext = _hostext.module()                             # native host path: event pairs are recorded inside the extension
+        self._pair = None                                        # (begin, end) torch events of the NEXT launch, or None
+        _native.set_launch_hook(None)
+        if not args.engine_threads:
+            torch.autograd.set_multithreading_enabled(False)
+        # the two-stream legs visit the same leaf inputs from alternating streams on purpose; torch >= 2.9 warns about the
+        # AccumulateGrad node's stream then (once per process, a paragraph on stderr)
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
+        # `value` is the training-loop figure: loss.backward() through PyTorch's autograd engine (what a network output gets;
+        # one kernel launch per step: losses._FusedLossTensor)
+        losses._UNIT_GRADIENT = True
+
+    def _hook(self, phase):                                      # ctypes host path: called around the launch
+        if self._pair is not None:
+            self._pair[0 if phase == "begin" else 1].record(torch.cuda.current_stream(self.dev))
+
+    def step(self):
+        k = self.k
+        self.k = k + 1
+        if self.ns:
+            torch.cuda.set_stream(self.streams[k % self.ns])     # the whole step (launch, backward) is issued on this stream
+        inp, tgt = self.batches[k % len(self.batches)]
         inp.grad = None
-        loss = loss_fn(inp, tgt)
+        loss = self.loss_fn(inp, tgt)
         loss.backward()
         return loss
 
-    if not args.engine_threads:
-        torch.autograd.set_multithreading_enabled(False)
-    # the two-stream legs visit the same leaf inputs from alternating streams on purpose; torch >= 2.9 warns about the
-    # AccumulateGrad node's stream then (once per process, a paragraph on stderr)
-    quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-    if quiet is not None:
-        quiet(False)
-    # `value` is the training-loop figure: loss.backward() through PyTorch's autograd engine (what a network output gets; one
-    # kernel launch per step: losses._FusedLossTensor).  (Rounds 1-5 timed an engine-free shortcut for leaf inputs; removed in
-    # round 6 -- the engine entered from the extension is as fast.)
-    losses._UNIT_GRADIENT = True
-    torch.cuda.synchronize(dev)               # inputs were produced on the default stream
-    t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:      # untimed, see --settle-ms
-        for _ in range(64):
-            step()
-        torch.cuda.synchronize(dev)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    # ---- the timed region(s).  One region = EXACTLY --steps steps between barrier + synchronize on both sides, its time the
-    # MAX over ranks.  The default form (2000 steps, 75 ms) times one.  A SHORT form (the driver's --steps 20 is 0.76 ms of
-    # GPU time) times N_REGIONS such regions back to back and reports the MEDIAN region: a single 0.8 ms region swung by
-    # +-6 % between runs on one box in round 4 (197-224 k), SURVEY 8d asks for a median over >= 100 iterations, and nine (since late round 6: fifteen)
-    # regions of 20 steps are 180.  Every region is listed in the JSON line (`timed_regions`).
+    def back_to_default_stream(self):
+        if self.ns:
+            torch.cuda.set_stream(torch.cuda.default_stream(self.dev))
+
+    def settle_and_warm_up(self, settle_ms, warmup):
+        torch.cuda.synchronize(self.dev)               # inputs were produced on the default stream
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < settle_ms:      # untimed, see --settle-ms
+            for _ in range(64):
+                self.step()
+            torch.cuda.synchronize(self.dev)
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize(self.dev)
+
+    def run_sampled(self, n, stride):
+        """an UNTIMED leg of n steps with a HIP event pair around every stride-th launch -> (sorted ms per bracketed launch,
+        wall ms per step of the leg)"""
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % stride == 0 else None
+                 for i in range(n)]
+        if self.ext is not None:
+            for p in pairs:                       # create the raw hipEvent handles once
+                if p is not None:
+                    p[0].record()
+                    p[1].record()
+            torch.cuda.synchronize(self.dev)
+        else:
+            self._native.set_launch_hook(self._hook)
+        t0 = time.perf_counter()
+        for p in pairs:
+            if p is not None:
+                if self.ext is not None:
+                    self.ext.set_timing_events(p[0].cuda_event, p[1].cuda_event)
+                else:
+                    self._pair = p
+            self.step()
+            self._pair = None
+        torch.cuda.synchronize(self.dev)
+        wall_ms = 1e3 * (time.perf_counter() - t0) / n
+        self._native.set_launch_hook(None)
+        self.back_to_default_stream()
+        return sorted(p[0].elapsed_time(p[1]) for p in pairs if p is not None), wall_ms
+
+
+def timed_regions(args, R, loop):
+    """THE measurement.  One region = EXACTLY --steps steps between barrier + synchronize on both sides, its time the MAX over
+    ranks.  The default form (2000 steps, 75 ms) times one.  A SHORT form (the driver's --steps 20 is 0.76 ms of GPU time)
+    times `--regions` such regions back to back and the MEDIAN region is reported: a single 0.8 ms region swung by +-6 %
+    between runs on one box in round 4 (197-224 k), SURVEY 8d asks for a median over >= 100 iterations, and a host hiccup of a
+    shared box costs a whole region.  Every region is listed in the JSON line (`timed_regions`).
+    -> n_regions, per-region local wall seconds, per-region HIP-event ms per launch (None with several streams), last losses"""
     n_regions = 1 if args.steps >= 256 else max(9, args.regions)
+    dev = loop.dev
     local_elapsed, region_ms, lasts = [], [], []
-    for r in range(n_regions):
-        if dist is not None:
-            barrier()
+    for _ in range(n_regions):
+        R.barrier()
         torch.cuda.synchronize(dev)
         # one HIP event pair around the WHOLE region, on the stream the kernels are launched on (one stream only: with N
-        # streams there is no single stream that sees every launch): region / launches is the average launch duration
-        # including the ~1 us between back-to-back launches, without the end-of-pipe bubbles of per-launch events
-        region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if not ns else None
+        # streams there is no single stream that sees every launch): a secondary figure (time_per_launch_ms), without the
+        # barrier / synchronize / host tail of the region
+        region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if not loop.ns else None
         t0 = time.perf_counter()
         if region:
             region[0].record(torch.cuda.current_stream(dev))
-        for i in range(args.steps):
-            if sample_in_region:
-                state["i"] = i
-            last = step()
-        state["i"] = -1
+        for _i in range(args.steps):
+            last = loop.step()
         if region:
             region[1].record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
         local_elapsed.append(time.perf_counter() - t0)   # this rank's K steps are done; the job's time is the MAX over ranks
-        if dist is not None:
-            barrier()                       # closing bracket: every rank has finished before anything else happens
+        R.barrier()                         # closing bracket: every rank has finished before anything else happens
         torch.cuda.synchronize(dev)
         region_ms.append(region[0].elapsed_time(region[1]) / args.steps if region else None)
         lasts.append(last)
-    if ns:
-        torch.cuda.set_stream(torch.cuda.default_stream(dev))
-    _native.set_launch_hook(None)
-    per_rank = None
+    loop.back_to_default_stream()
+    return n_regions, local_elapsed, region_ms, lasts
+
+
+def reduce_over_ranks(args, R, loop, local_elapsed, region_ms, lasts):
+    """MAX over ranks of every region's time, the median region, and the per-rank record of it"""
+    from svbrdf_estimation_amd import distributed
+    B = args.batch
     job_elapsed = list(local_elapsed)
-    if dist is not None:
-        where = dev if nccl else "cpu"
+    if R.dist is not None:
+        where = loop.dev if R.nccl else "cpu"
         t = torch.tensor(local_elapsed, dtype=torch.float64, device=where)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)            # per region: the slowest rank's time
+        R.dist.all_reduce(t, op=R.dist.ReduceOp.MAX)            # per region: the slowest rank's time
         job_elapsed = [float(v) for v in t.tolist()]
     median_region = median_region_index(job_elapsed)
     elapsed, last = job_elapsed[median_region], lasts[median_region]
-    region_ms_per_launch = region_ms[median_region]
-    if dist is not None:
-        mine = torch.tensor([local_elapsed[median_region], float(last.item()), float(distributed.rank_seed(313, rank))],
+    if R.dist is not None:
+        mine = torch.tensor([local_elapsed[median_region], float(last.item()), float(distributed.rank_seed(313, R.rank))],
                             dtype=torch.float64, device=where)
-        mean_loss = distributed.global_mean(last.detach() if nccl else last.detach().cpu()).item()
-        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
-        dist.all_gather(every, mine)            # for the record: each rank's own clock, last loss and scene seed
-        places = [None] * dist.get_world_size()
-        dist.all_gather_object(places, placement)
+        mean_loss = distributed.global_mean(last.detach() if R.nccl else last.detach().cpu()).item()
+        every = [torch.zeros_like(mine) for _ in range(R.dist.get_world_size())]
+        R.dist.all_gather(every, mine)            # for the record: each rank's own clock, last loss and scene seed
+        places = R.gather(R.placement)
         per_rank = {"elapsed_s": [float(e[0]) for e in every],
                     "ms_per_step": [1e3 * float(e[0]) / args.steps for e in every],
                     "patches_per_s": [B * args.steps / float(e[0]) for e in every],
@@ -662,159 +693,155 @@ def main():
     else:
         mean_loss = last.item()
         per_rank = {"elapsed_s": [elapsed], "ms_per_step": [1e3 * elapsed / args.steps],
-                    "patches_per_s": [B * args.steps / elapsed], "cpus": [placement["cpus"]],
-                    "numa_node": [placement["numa_node"]], "cpu_binding": [placement["source"]],
-                    "pci_crosscheck": [placement.get("pci_crosscheck")]}
+                    "patches_per_s": [B * args.steps / elapsed], "cpus": [R.placement["cpus"]],
+                    "numa_node": [R.placement["numa_node"]], "cpu_binding": [R.placement["source"]],
+                    "pci_crosscheck": [R.placement.get("pci_crosscheck")]}
+    return job_elapsed, median_region, elapsed, region_ms[median_region], mean_loss, per_rank
 
-    if not sample_in_region and not args.timed_only:     # untimed: the per-launch event samples no timed region carries
-        _native.set_launch_hook(hook)
-        for i in range(n_sample_leg):
-            state["i"] = i
-            step()
-        state["i"] = -1
+
+def clock_leg(loop, ms_guess):
+    """The clock the chip holds under this kernel is not one number: it moves between 2.0 and 2.4 GHz within milliseconds
+    (power management), differs by box, and sags to ~1.75 GHz for ~5 ms when load arrives after an idle period
+    (tools/clock_timeline.py, profiles/r05_clock_timeline*.txt).  Cycles per launch therefore need clock and duration from
+    the SAME interval: an event A on the loop's stream opens the interval, the probe stream waits for A and then spins the
+    one-wave probe for ~3 ms, and an event B closes the interval after as many steps as run in that time.  (Rounds 1-4
+    paired the timed region's duration with a clock read in a later interval: good to +-8 %.)
+    -> clock GHz | None, how it was measured, ms per launch of that very interval | None"""
+    dev, native = loop.dev, loop._native
+    clock_ghz, note, leg_ms = None, "not measured", None
+    try:
+        probe_stream = torch.cuda.Stream(dev)
+        probe_out = torch.zeros(2, dtype=torch.int64, device=dev)
+        native.clock_probe(probe_out, ticks=1, stream=probe_stream)     # first use loads the probe kernel (~6 ms of host time): not inside the interval
         torch.cuda.synchronize(dev)
-        _native.set_launch_hook(None)
-        if ns:
-            torch.cuda.set_stream(torch.cuda.default_stream(dev))
-    kernel_ms = sorted(p[0].elapsed_time(p[1]) for p in ev if p is not None) if not args.timed_only else []
-    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms) if kernel_ms else None
+        k_leg = int(max(16, min(4096, 3.2 / ms_guess)))        # steps that fill the probe's 3 ms (and a little more)
+        for _ in range(max(64, k_leg, int(12.0 / ms_guess))):   # >= 12 ms of load first: past the onset sag, queue deep when A is recorded
+            loop.step()
+        ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        loop_stream = torch.cuda.current_stream(dev)
+        ev_a.record(loop_stream)
+        probe_stream.wait_event(ev_a)
+        native.clock_probe(probe_out, ticks=300000, stream=probe_stream)     # 3 ms of the 100 MHz counter, from A on
+        for _ in range(k_leg):
+            loop.step()
+        ev_b.record(loop_stream if not loop.ns else torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        cyc, ticks = (int(v) for v in probe_out.tolist())
+        if ticks > 0:
+            clock_ghz = cyc / ticks * 0.1
+            leg_ms = ev_a.elapsed_time(ev_b) / k_leg if not loop.ns else None
+            note = ("measured in this run: s_memtime / s_memrealtime of a one-wave probe kernel spinning %.1f ms on its own "
+                    "stream beside %d steps of the bench loop, probe and steps opened by the same event (clock and duration "
+                    "of one interval)" % (ticks * 1e-5, k_leg))
+    except Exception as e:  # pragma: no cover
+        note = "probe failed: %r" % (e,)
+    loop.back_to_default_stream()
+    return clock_ghz, note, leg_ms
 
-    # defaults of everything the follow-up legs produce (--timed-only skips them: the profiler passes, whose per-kernel average
-    # should be the timed loop's launches and nothing else)
-    main_ns = ns
-    clock_ghz, clock_note, cycle_leg_ms = None, "not measured (--timed-only)", None
+
+def other_issue_pattern_leg(loop, steps):
+    """the OTHER way of issuing the steps than the timed region's: it ran them on one stream -> now alternating on two (one
+    step's kernel fills the ramp and tail of the other's: a bench-loop property), and vice versa"""
+    main_ns = loop.ns
+    loop.ns = 2 if main_ns == 0 else 0
+    n = max(80, min(steps, 1024))
+    stride = max(1, min(16 if loop.ns == 0 else 32, n // 5))
+    for _ in range(32):                         # let the other issue pattern reach its steady state
+        loop.step()
+    torch.cuda.synchronize(loop.dev)
+    ms, wall_ms = loop.run_sampled(n, stride)
+    loop.ns = main_ns
+    return wall_ms, ms, n
+
+
+def backward_mode_leg(loop, unit, n):
+    """an untimed leg on one stream with HIP events around it: the engine with the unit gradient (the timed region's own mode:
+    one launch per step) or with its own ones-fill kernel and the node's no-op scale launch (rounds 1-4: three kernels)"""
+    main_ns, loop.ns = loop.ns, 0
+    loop.losses._UNIT_GRADIENT = unit
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < 20e-3:       # past the clock sag that follows a synchronize (DESIGN section 4.4)
+        for _ in range(32):
+            loop.step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream(loop.dev))      # no synchronize in front: the loop keeps running into the timed steps
+    for _ in range(n):
+        loop.step()
+    e1.record(torch.cuda.current_stream(loop.dev))
+    torch.cuda.synchronize(loop.dev)
+    loop.losses._UNIT_GRADIENT, loop.ns = True, main_ns
+    return e0.elapsed_time(e1) / n
+
+
+def main():
+    args = parse_args()
+    from svbrdf_estimation_amd import launch
+    if args.gpus > 1 and not launch.launched_as_rank():
+        # started as ONE plain process (`python bench.py --gpus N`): become the parent of N fresh rank processes.
+        # Nothing has initialised the GPU runtime in this process and nothing will (see launch.py).
+        os.environ["SVBRDF_SELF_SPAWNED"] = "1"
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    R = Rank(args)
+    if args.plumbing_only:
+        return plumbing_only(args, R.rank, R.world, R.placement)
+    R.attach_device_and_group(args)
+    if args.selftest:
+        return run_selftest(args, R)
+
+    loop = StepLoop(args, R)
+    loop.settle_and_warm_up(args.settle_ms, args.warmup)
+    n_regions, local_elapsed, region_ms, lasts = timed_regions(args, R, loop)
+    job_elapsed, median_region, elapsed, region_ms_per_launch, mean_loss, per_rank = reduce_over_ranks(
+        args, R, loop, local_elapsed, region_ms, lasts)
+
+    # ---- untimed follow-up legs (same process, same tensors).  --timed-only skips them: the profiler passes, whose per-kernel
+    # average should be the timed loop's launches and nothing else
+    main_ns = loop.ns
+    kernel_ms, clock_ghz, clock_note, cycle_leg_ms = [], None, "not measured (--timed-only)", None
     other_ms_per_step, other_ms, other_steps, leg_steps = None, [], 0, 0
-    engine_ms_per_step = engine_plain_ms_per_step = None
-    copy = None
+    engine_ms_per_step = engine_plain_ms_per_step = copy = None
     if not args.timed_only:
-        # ---- untimed follow-up phases (same process, same tensors): the shader clock under this load, and the OTHER way of
-        # issuing the steps (the timed region ran them on one stream -> now alternating on two, and vice versa)
-        state["i"] = -1
-        # The clock the chip holds under this kernel is not one number: it moves between 2.0 and 2.4 GHz within milliseconds
-        # (power management), differs by box, and sags to ~1.75 GHz for ~5 ms when load arrives after an idle period
-        # (tools/clock_timeline.py, profiles/r05_clock_timeline*.txt).  Cycles per launch therefore need clock and duration from
-        # the SAME interval: an event A on the loop's stream opens the interval, the probe stream waits for A and then spins the
-        # one-wave probe for ~3 ms, and an event B closes the interval after as many steps as run in that time.  (Rounds 1-4
-        # paired the timed region's duration with a clock read in a later interval: good to +-8 %.)
-        clock_ghz, clock_note, cycle_leg_ms = None, "not measured", None
-        try:
-            probe_stream = torch.cuda.Stream(dev)
-            probe_out = torch.zeros(2, dtype=torch.int64, device=dev)
-            _native.clock_probe(probe_out, ticks=1, stream=probe_stream)     # first use loads the probe kernel (~6 ms of host time): not inside the interval
-            torch.cuda.synchronize(dev)
-            ms_guess = min(local_elapsed) * 1e3 / args.steps
-            k_leg = int(max(16, min(4096, 3.2 / ms_guess)))        # steps that fill the probe's 3 ms (and a little more)
-            for _ in range(max(64, k_leg, int(12.0 / ms_guess))):   # >= 12 ms of load first: past the onset sag, queue deep when A is recorded
-                step()
-            ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            loop_stream = torch.cuda.current_stream(dev)
-            ev_a.record(loop_stream)
-            probe_stream.wait_event(ev_a)
-            _native.clock_probe(probe_out, ticks=300000, stream=probe_stream)     # 3 ms of the 100 MHz counter, from A on
-            for _ in range(k_leg):
-                step()
-            ev_b.record(loop_stream if not ns else torch.cuda.current_stream(dev))
-            torch.cuda.synchronize(dev)
-            cyc, ticks = (int(v) for v in probe_out.tolist())
-            if ticks > 0:
-                clock_ghz = cyc / ticks * 0.1
-                cycle_leg_ms = ev_a.elapsed_time(ev_b) / k_leg if not ns else None
-                clock_note = ("measured in this run: s_memtime / s_memrealtime of a one-wave probe kernel spinning %.1f ms on its own "
-                              "stream beside %d steps of the bench loop, probe and steps opened by the same event (clock and duration "
-                              "of one interval)" % (ticks * 1e-5, k_leg))
-        except Exception as e:  # pragma: no cover
-            clock_note = "probe failed: %r" % (e,)
-        if ns:
-            torch.cuda.set_stream(torch.cuda.default_stream(dev))
-        main_ns = ns
-        other_ns = 2 if main_ns == 0 else 0
-        other_steps = max(80, min(args.steps, 1024))
-        other_stride = max(1, min(16 if other_ns == 0 else 32, other_steps // 5))
-        ev_other = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % other_stride == 0 else None
-                    for i in range(other_steps)]
-        ns = other_ns
-        if ext is not None:
-            for pair in ev_other:
-                if pair is not None:
-                    pair[0].record()
-                    pair[1].record()
-            torch.cuda.synchronize(dev)
-        ev, raw_ev = ev_other, ([(p[0].cuda_event, p[1].cuda_event) if p is not None else None for p in ev_other]
-                                if ext is not None else [])
-        _native.set_launch_hook(hook)
-        for _ in range(32):                         # let the other issue pattern reach its steady state
-            step()
-        torch.cuda.synchronize(dev)
-        t_other = time.perf_counter()
-        for i in range(other_steps):
-            state["i"] = i
-            step()
-        state["i"] = -1
-        torch.cuda.synchronize(dev)
-        other_ms_per_step = 1e3 * (time.perf_counter() - t_other) / other_steps
-        _native.set_launch_hook(None)
-        if ns:
-            torch.cuda.set_stream(torch.cuda.default_stream(dev))
-        ns = main_ns
-        other_ms = sorted(p[0].elapsed_time(p[1]) for p in ev_other if p is not None)
-        # two more untimed legs, one stream, HIP events around each: the timed region's own mode once more (the engine with the
-        # unit gradient: one launch per step), and the engine with its own ones-fill kernel and the node's no-op scale launch
-        # (rounds 1-4: three kernels per step)
-        saved_ns, ns = ns, 0
+        kernel_ms, _ = loop.run_sampled(512, 16)                 # event pairs around every 16th launch of 512 untimed steps
+        clock_ghz, clock_note, cycle_leg_ms = clock_leg(loop, min(local_elapsed) * 1e3 / args.steps)
+        other_ms_per_step, other_ms, other_steps = other_issue_pattern_leg(loop, args.steps)
         leg_steps = max(600, other_steps)
-
-        def backward_mode_leg(unit):
-            losses._UNIT_GRADIENT = unit
-            t_settle = time.perf_counter()
-            while time.perf_counter() - t_settle < 20e-3:       # past the clock sag that follows the synchronize above (section 4.4)
-                for _ in range(32):
-                    step()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream(dev))           # no synchronize in front: the loop keeps running into the timed steps
-            for _ in range(leg_steps):
-                step()
-            e1.record(torch.cuda.current_stream(dev))
-            torch.cuda.synchronize(dev)
-            return e0.elapsed_time(e1) / leg_steps
-        engine_ms_per_step = backward_mode_leg(True)
-        engine_plain_ms_per_step = backward_mode_leg(False)
-        losses._UNIT_GRADIENT, ns = True, saved_ns
-
-        # the copy bandwidth of this box, measured in this run (rank 0's GPU; untimed leg)
-        copy = None
-        if rank == 0 and not args.no_copy_peak:
+        engine_ms_per_step = backward_mode_leg(loop, True, leg_steps)
+        engine_plain_ms_per_step = backward_mode_leg(loop, False, leg_steps)
+        if R.rank == 0 and not args.no_copy_peak:               # the copy bandwidth of this box, measured in this run
             try:
-                copy = copy_peak(dev)
+                copy = copy_peak(loop.dev)
             except Exception as e:  # pragma: no cover
                 copy = {"GBps": None, "error": repr(e)}
 
-    if rank == 0:
+    if R.rank == 0:
         out, copy_gbps = assemble_line(args, {
-            "B": B, "H": H, "S": S, "world": world, "n_batches": len(batches), "elapsed": elapsed, "job_elapsed": job_elapsed,
-            "median_region": median_region, "n_regions": n_regions, "kernel_ms": kernel_ms, "kernel_ms_avg": kernel_ms_avg,
+            "B": args.batch, "H": args.size, "S": args.random_scenes + args.specular_scenes, "world": R.world,
+            "n_batches": len(loop.batches), "elapsed": elapsed, "job_elapsed": job_elapsed,
+            "median_region": median_region, "n_regions": n_regions, "kernel_ms": kernel_ms,
+            "kernel_ms_avg": sum(kernel_ms) / len(kernel_ms) if kernel_ms else None,
             "region_ms_per_launch": region_ms_per_launch, "main_ns": main_ns, "clock_ghz": clock_ghz,
             "clock_note": clock_note, "cycle_leg_ms": cycle_leg_ms, "other_ms_per_step": other_ms_per_step, "other_ms": other_ms,
             "other_steps": other_steps, "leg_steps": leg_steps,
             "engine_ms_per_step": engine_ms_per_step, "engine_plain_ms_per_step": engine_plain_ms_per_step, "copy": copy,
-            "mean_loss": mean_loss, "per_rank": per_rank, "ranks_seen": ranks_seen,
-            "process_group": ("%s (%s), world size %d" % (args.backend, "RCCL" if nccl else "CPU transport, plumbing only",
-                                                          dist.get_world_size())) if dist is not None else None,
-            "host_path": "native C++ extension (csrc/host_ext.cpp)" if ext is not None else "python + ctypes"})
+            "mean_loss": mean_loss, "per_rank": per_rank, "ranks_seen": R.ranks_seen,
+            "process_group": ("%s (%s), world size %d" % (args.backend, "RCCL" if R.nccl else "CPU transport, plumbing only",
+                                                          R.dist.get_world_size())) if R.dist is not None else None,
+            "host_path": "native C++ extension (csrc/host_ext.cpp)" if loop.ext is not None else "python + ctypes"})
         t_main = time.perf_counter()
-        if world == 1 and not args.no_secondary:
-            out["secondary"] = secondary_kernels(dev, H, copy_gbps)
+        if R.world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_kernels(loop.dev, args.size, copy_gbps)
         t_secondary = time.perf_counter()
-        if world == 1 and not args.no_cpu_baseline:
-            os.sched_setaffinity(0, host_cpus)      # "the host cores of the box", not the GPU's socket only
-            table = loss_fn.sample_scene_table(B)
-            out["cpu_baseline"] = cpu_baseline(args, inp_h, tgt_h, table)
+        if R.world == 1 and not args.no_cpu_baseline:
+            os.sched_setaffinity(0, R.host_cpus)      # "the host cores of the box", not the GPU's socket only
+            table = loop.loss_fn.sample_scene_table(args.batch)
+            out["cpu_baseline"] = cpu_baseline(args, loop.inp_h, loop.tgt_h, table)
         else:
             out["cpu_baseline"] = None
         out["wall_s"] = {"imports_to_main": T_IMPORTED - T_PROCESS_START, "gpu_legs": t_main - T_IMPORTED,
                          "secondary": t_secondary - t_main, "cpu_baseline": time.perf_counter() - t_secondary}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if R.dist is not None:
+        R.dist.destroy_process_group()
 
 
 if __name__ == "__main__":
