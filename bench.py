@@ -639,13 +639,20 @@ def timed_regions(args, R, loop):
     n_regions = 1 if args.steps >= 256 else max(9, args.regions)
     dev = loop.dev
     local_elapsed, region_ms, lasts = [], [], []
-    for _ in range(n_regions):
+    # one HIP event pair around each WHOLE region, on the stream the kernels are launched on (one stream only: with N streams
+    # there is no single stream that sees every launch): a secondary figure (time_per_launch_ms), without the barrier /
+    # synchronize / host tail of the region.  Created (a torch event is created at its first record) before anything is
+    # timed: inside a 0.74 ms region two event creations would be 1 % of it.
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if not loop.ns else None
+             for _ in range(n_regions)]
+    for p in pairs:
+        if p is not None:
+            p[0].record(torch.cuda.current_stream(dev))
+            p[1].record(torch.cuda.current_stream(dev))
+    torch.cuda.synchronize(dev)
+    for region in pairs:
         R.barrier()
         torch.cuda.synchronize(dev)
-        # one HIP event pair around the WHOLE region, on the stream the kernels are launched on (one stream only: with N
-        # streams there is no single stream that sees every launch): a secondary figure (time_per_launch_ms), without the
-        # barrier / synchronize / host tail of the region
-        region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if not loop.ns else None
         t0 = time.perf_counter()
         if region:
             region[0].record(torch.cuda.current_stream(dev))
