@@ -181,4 +181,6 @@ if all(os.path.exists(x) for x in parts):
         for x, title in zip(parts, ("=== sleep OFF (-DSVBRDF_K3_STAGGER=0): what the review asked for ===\n",
                                     "=== sleep ON (the shipped stagger; stamps are taken before it) ===\n")):
             f.write(title + "".join(l for l in open(x) if "amdgpu.ids" not in l) + "\n")
+    for x in parts:             # the combined file is the evidence
+        os.remove(x)
 print("wrote", sorted(os.listdir(P)))
