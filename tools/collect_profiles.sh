@@ -29,6 +29,9 @@ BENCH="python3 $R/bench.py --no-cpu-baseline --no-secondary --timed-only"
 # exceeds a launch's share of the GPU: what bench.py reports as two_streams_overlapped)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats --output-format csv -- $BENCH --steps 400 --warmup 50 > $OUT/${TAG}_stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats2 --output-format csv -- $BENCH --steps 400 --warmup 50 --streams 2 > $OUT/${TAG}_stats2.log 2>&1
+# ... and of the DEFAULT command as it is (2,000 steps, every untimed follow-up leg included): the verbatim average then mixes
+# in the overlapped launches of the two-stream leg, so the summary also splits the per-dispatch trace by stream
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_statsdef --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-secondary > $OUT/${TAG}_statsdef.log 2>&1
 # the counter passes run one launch at a time (--streams 1) over the six rotating batches (302 MB: beyond the Infinity Cache)
 BENCH="$BENCH --streams 1"
 # HBM traffic: FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots)

@@ -45,6 +45,24 @@ if st:
                     k[0], k[1], len(v), sum(v) / len(v), min(v), max(v),
                     "the launch stream of the timed region: one launch at a time" if k == main else
                     "a stream of the untimed two-stream follow-up leg: launches overlap"))
+sd = one("%s_statsdef/*/*_kernel_stats.csv" % tag)
+if sd:      # the default command verbatim, and its fused-loss launches split by stream
+    shutil.copy(sd, os.path.join(P, "%s_kernel_stats_default_command.csv" % tag))
+    tr = sd.replace("_kernel_stats.csv", "_kernel_trace.csv")
+    if os.path.exists(tr):
+        by = collections.defaultdict(list)
+        for r in csv.DictReader(open(tr)):
+            if "k_rendering_loss" in r["Kernel_Name"]:
+                by[(r["Queue_Id"], r["Stream_Id"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        with open(os.path.join(P, "%s_kernel_stats_default_command_by_stream.csv" % tag), "w") as f:
+            f.write('"Kernel","Queue_Id","Stream_Id","Calls","AverageNs","MinNs","MaxNs","Note"\n')
+            main = max(by, key=lambda k: len(by[k])) if by else None
+            for k in sorted(by, key=lambda k: -len(by[k])):
+                v = by[k]
+                f.write('"k_rendering_loss*",%s,%s,%d,%.1f,%d,%d,"%s"\n' % (
+                    k[0], k[1], len(v), sum(v) / len(v), min(v), max(v),
+                    "the launch stream of settle, warm-up, the timed region and the one-stream follow-up legs: one launch at a time" if k == main else
+                    "a stream of the untimed two-stream follow-up leg: launches overlap"))
 st1 = one("%s_stats1/*/*_kernel_stats.csv" % tag)
 if st1:
     shutil.copy(st1, os.path.join(P, "%s_kernel_stats_streams1.csv" % tag))      # round 2 layout: --streams 1 beside a two-stream default
